@@ -1,0 +1,381 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels
+to the GPU box).  The reference is imported unmodified; the harness below
+only (a) provides empty stand-ins for third-party *Python packages that are
+not installed and are not on the english hot path* (boto3/botocore: S3 cache,
+ftfy: tokenizer text cleanup) and maps `diffdist.functional.all_gather`
+(un-vendored, requirements.txt:3) onto torch.distributed.nn.functional.all_gather,
+(b) replaces the two loaders that need the network (CLIP.get_config download,
+AutoConfig hub fetch) by synthetic CLIP-shaped weights / a local config.json,
+(c) patches torch for CPU: Tensor.cuda -> identity (modeling.py:311),
+SyncBatchNorm conversion -> no-op (identical numerics at world size 1).
+
+Outputs are plain arrays (.npz) — inputs/weights are regenerated from seeds by
+hmmc_amd/synth.py on both sides and never stored.
+
+    python tests/golden/make_golden.py [--only NAME]
+"""
+import argparse
+import importlib.machinery
+import json
+import os
+import sys
+import tempfile
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from hmmc_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    import torch.distributed as dist
+    import torch.distributed.nn.functional as dnf
+    _stub("boto3")
+    b = _stub("botocore")
+    b.exceptions = _stub("botocore.exceptions", ClientError=Exception)
+    _stub("ftfy", fix_text=lambda s: s)
+    f = _stub("diffdist.functional", all_gather=lambda out_list, x: list(dnf.all_gather(x)))
+    _stub("diffdist", functional=f)
+    sys.path.insert(0, REF)
+    if not dist.is_initialized():
+        store = tempfile.mktemp(prefix="hmmc_golden_store_")
+        dist.init_process_group("gloo", init_method=f"file://{store}", rank=0, world_size=1)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.SyncBatchNorm.convert_sync_batchnorm = classmethod(lambda cls, module, process_group=None: module)
+    import modules.module_clip as mclip
+    import modules.modeling as mmodel
+    import modules.optimization as mopt
+    import metrics as mmetrics
+    return mclip, mmodel, mopt, mmetrics
+
+
+def task_config(**kw):
+    d = dict(local_rank=0, rank=0, use_temp=True, language="english", top_frames=2, max_frames=4, n_display=100000,
+             logdir=None, use_frame_fea=True, dataset="msrvtt", contrast_momentum=0.99, contrast_temperature=0.07,
+             contrast_num_negative=16, pretrained_text=None, lr=1e-4, text_lr=3e-5, coef_lr=1e-3, weight_decay=0.2,
+             warmup_proportion=0.1)
+    d.update(kw)
+    return Namespace(**d)
+
+
+def build_reference_model(mclip, cls, dims, sd, mode, **tc):
+    """Construct the reference model with synthetic weights and load the full synthetic state."""
+    clip_sd = synth.clip_state_from(sd, dims)
+    mclip.CLIP.get_config = staticmethod(lambda pretrained_clip_name="ViT-B/32": {k: v.clone() for k, v in clip_sd.items()})
+    cfg = task_config(**tc)
+    if cfg.pretrained_text is None:
+        d = tempfile.mkdtemp(prefix="hmmc_textcfg_")
+        with open(os.path.join(d, "config.json"), "w") as fh:
+            json.dump({"model_type": "bert", "hidden_act": "gelu"}, fh)
+        cfg.pretrained_text = d
+    model = cls.from_pretrained("cross-base", cache_dir=tempfile.mkdtemp(), state_dict=None, task_config=cfg)
+    missing, unexpected = model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all("t_projector" in k for k in missing) or not missing, missing
+    if mode == "fp32":
+        model.float()
+        model.text_encoder.dtype = torch.float32
+        if hasattr(model, "text_encoder_k"):
+            model.text_encoder_k.dtype = torch.float32
+    model.train()
+    return model, cfg
+
+
+def grad_norms(model):
+    return {n: float(p.grad.float().norm()) for n, p in model.named_parameters() if p.grad is not None}
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().float().numpy() if v.is_floating_point() else v.detach().numpy()
+        out[k] = v
+    out["_versions"] = np.array(f"torch {torch.__version__} numpy {np.__version__}")
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------- fixtures
+
+def fx_head(mclip, mmodel, mopt, mmetrics):
+    dims = synth.TINY
+    sd = synth.finetune_state(dims)
+    model, _ = build_reference_model(mclip, mmodel.BirdModel, dims, sd, "fp32")
+    for tag, B, Fr in (("head_ft_small", 48, 5), ("head_ft_c2", 256, 12)):
+        q = synth.normal(f"{tag}.q", (B, 512)).requires_grad_()
+        v = synth.normal(f"{tag}.v", (B, 512)).requires_grad_()
+        u = synth.normal(f"{tag}.u", (B, Fr, 512)).requires_grad_()
+        fl = model.frame_loss(q, u)
+        s = model.loose_similarity(q, v)
+        sl = model.loss_fct(s) + model.loss_fct(s.T)
+        loss = model.weight_FTM_finetune * fl + model.weight_VTM_finetune * sl
+        loss.backward()
+        s0 = model.loose_similarity(q, u[:, 0, :])
+        if B <= 64:
+            save(tag, B=B, F=Fr, loss=loss, frame_loss=fl, sim_loss=sl, S_video=s, S_frame0=s0,
+                 dQ=q.grad, dV=v.grad, dU=u.grad)
+        else:
+            save(tag, B=B, F=Fr, loss=loss, frame_loss=fl, sim_loss=sl, S_video_rows=s[:8], S_frame0_rows=s0[:8],
+                 dQ_rows=q.grad[:8], dV_rows=v.grad[:8], dU_rows=u.grad[:4], dQ_norm=q.grad.norm(), dV_norm=v.grad.norm(),
+                 dU_norm=u.grad.norm())
+    # eval scorer + metrics (main_task_retrieval.py:332-336, metrics.py:12-39)
+    q = synth.normal("head_eval.q", (48, 512))
+    v = synth.normal("head_eval.v", (48, 512))
+    u = synth.normal("head_eval.u", (48, 12, 512))
+    # make it a retrieval problem with structure: text i is close to video i
+    q = q + 0.7 * v
+    out = {}
+    with torch.no_grad():
+        sv = model.loose_similarity(q, v)
+        sf = model.loose_similarity(q, u)
+        out["S_video"], out["S_frame"] = sv, sf
+        for k in (1, 2, 3, 12):
+            fk = torch.topk(sf, k=k, dim=2)[0].mean(dim=2)
+            out[f"topk{k}"] = fk
+            mt = mmetrics.compute_metrics((sv + fk).numpy())
+            out[f"metrics{k}"] = np.array([mt["R1"], mt["R5"], mt["R10"], mt["MR"], mt["MeanR"]])
+        mt = mmetrics.compute_metrics(sv.numpy())
+        out["metrics_video"] = np.array([mt["R1"], mt["R5"], mt["R10"], mt["MR"], mt["MeanR"]])
+        mt = mmetrics.compute_metrics(sv.numpy().T)
+        out["metrics_video_v2t"] = np.array([mt["R1"], mt["R5"], mt["R10"], mt["MR"], mt["MeanR"]])
+    save("head_eval", **out)
+
+
+def _enc_fixture(mclip, mmodel, name, dims, B, Fr, L, modes, use_temp=True):
+    sd = synth.finetune_state(dims, use_temp=use_temp)
+    ids, mask, vid, vf, idx = synth.finetune_batch(B, Fr, L, dims.image_res, tag=name)
+    for mode in modes:
+        model, _ = build_reference_model(mclip, mmodel.BirdModel, dims, sd, mode, use_temp=use_temp, max_frames=Fr)
+        q = model.text_encoder(ids, mask)
+        v, u = model.visual_encoder(vid, vf)
+        loss = model(ids, mask, vid, vf, idx, 1)
+        loss.backward()
+        gn = grad_norms(model)
+        names = sorted(gn)
+        P = dict(model.named_parameters())
+        sl = {}
+        for key, slc in (("text_encoder.text_projection", (slice(0, 4), slice(0, 8))),
+                         ("visual_encoder.visual.conv1.weight", (slice(0, 2), 0, slice(0, 4), slice(0, 4))),
+                         ("visual_encoder.visual.class_embedding", (slice(0, 8),)),
+                         ("visual_encoder.visual.positional_embedding", (slice(0, 3), slice(0, 8))),
+                         ("visual_encoder.visual.ln_pre.weight", (slice(0, 8),)),
+                         ("visual_encoder.visual.transformer.resblocks.0.attn.in_proj_weight", (slice(0, 4), slice(0, 8))),
+                         ("visual_encoder.visual.transformer.resblocks.0.mlp.c_fc.bias", (slice(0, 8),)),
+                         ("text_encoder.transformer.resblocks.1.attn.out_proj.weight", (slice(0, 4), slice(0, 8))),
+                         ("text_encoder.positional_embedding", (slice(0, 3), slice(0, 8))),
+                         ("visual_encoder.visual.proj", (slice(0, 4), slice(0, 8)))):
+            if key in P and P[key].grad is not None:
+                sl["g:" + key] = P[key].grad[slc]
+        if use_temp:
+            k = "visual_encoder.temporal_transformer.resblocks.0.mlp.c_fc.weight"
+            sl["g:" + k] = P[k].grad[:4, :8]
+            k = "visual_encoder.frame_position_embeddings.weight"
+            sl["g:" + k] = P[k].grad[:3, :8]
+        tg = P["text_encoder.token_embedding.weight"].grad
+        sl["g:text_encoder.token_embedding.weight[SOT]"] = tg[synth.SOT, :8]
+        sl["g:text_encoder.token_embedding.weight[EOT]"] = tg[synth.EOT, :8]
+        save(f"{name}_{mode}", dims=json.dumps(dims.to_dict()), B=B, F=Fr, L=L, text_feat=q, video_emb=v, frame_output=u,
+             loss=loss, grad_norm_names=np.array(names), grad_norm_values=np.array([gn[n] for n in names]), **sl)
+
+
+def fx_enc_tiny(mclip, mmodel, mopt, mmetrics):
+    _enc_fixture(mclip, mmodel, "enc_tiny", synth.TINY, 4, 4, 32, ("fp32", "aswritten"))
+    _enc_fixture(mclip, mmodel, "enc_tiny_notemp", synth.TINY, 3, 2, 20, ("fp32",), use_temp=False)
+
+
+def fx_enc_tiny16(mclip, mmodel, mopt, mmetrics):
+    _enc_fixture(mclip, mmodel, "enc_tiny16", synth.TINY16, 2, 3, 32, ("fp32", "aswritten"))
+
+
+def fx_enc_b32(mclip, mmodel, mopt, mmetrics):
+    _enc_fixture(mclip, mmodel, "enc_b32", synth.VIT_B32, 2, 2, 32, ("fp32", "aswritten"))
+
+
+def fx_bertadam(mclip, mmodel, mopt, mmetrics):
+    out = {}
+    specs = [("a32", (37,), torch.float32, 0.2, 1e-4, 3.0), ("b32", (8, 9), torch.float32, 0.0, 3e-5, 0.01),
+             ("c16", (64,), torch.float16, 0.2, 1e-4, 2.0), ("d16", (5, 16), torch.float16, 0.0, 1e-7, 0.05)]
+    params, groups = [], []
+    for name, shape, dt, wd, lr, gscale in specs:
+        p = torch.nn.Parameter(synth.normal(f"bertadam.{name}.p", shape, 0.5).to(dt))
+        params.append(p)
+        groups.append({"params": [p], "weight_decay": wd, "lr": lr})
+    opt = mopt.BertAdam(groups, lr=1e-4, warmup=0.1, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6, t_total=20,
+                        weight_decay=0.2, max_grad_norm=1.0)
+    for step in range(5):
+        for (name, shape, dt, wd, lr, gscale), p in zip(specs, params):
+            p.grad = synth.normal(f"bertadam.{name}.g{step}", shape, gscale).to(dt)
+        opt.step()
+        out[f"lr{step}"] = np.array(opt.get_lr())
+        for (name, *_), p in zip(specs, params):
+            st = opt.state[p]
+            out[f"{name}.p{step}"], out[f"{name}.m{step}"], out[f"{name}.v{step}"] = p.data, st["next_m"], st["next_v"]
+            out[f"{name}.g{step}"] = p.grad
+    save("bertadam", **out)
+
+
+def _prep_optimizer(mopt, model, cfg, t_total):
+    """main_task_retrieval.py:171-205 grouping, verbatim semantics."""
+    named = list(model.named_parameters())
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    dec = [(n, p) for n, p in named if not any(nd in n for nd in no_decay)]
+    nod = [(n, p) for n, p in named if any(nd in n for nd in no_decay)]
+    wd = cfg.weight_decay
+    lrc = cfg.lr * cfg.coef_lr
+    groups = [
+        {"params": [p for n, p in dec if "visual_encoder.visual." in n], "weight_decay": wd, "lr": lrc},
+        {"params": [p for n, p in dec if "text_encoder." in n], "weight_decay": wd, "lr": cfg.text_lr},
+        {"params": [p for n, p in dec if "visual_encoder.visual." not in n and "text_encoder." not in n], "weight_decay": wd},
+        {"params": [p for n, p in nod if "visual_encoder.visual." in n], "weight_decay": 0.0, "lr": lrc},
+        {"params": [p for n, p in nod if "text_encoder." in n], "weight_decay": 0.0, "lr": cfg.text_lr},
+        {"params": [p for n, p in nod if "visual_encoder.visual." not in n and "text_encoder." not in n], "weight_decay": 0.0},
+    ]
+    return mopt.BertAdam(groups, lr=cfg.lr, warmup=cfg.warmup_proportion, schedule="warmup_cosine", b1=0.9, b2=0.98,
+                         e=1e-6, t_total=t_total, weight_decay=wd, max_grad_norm=1.0)
+
+
+SAMPLED = ["text_encoder.text_projection", "visual_encoder.visual.conv1.weight", "visual_encoder.visual.class_embedding",
+           "visual_encoder.visual.transformer.resblocks.1.mlp.c_proj.weight",
+           "visual_encoder.visual.transformer.resblocks.0.ln_1.weight",
+           "visual_encoder.temporal_transformer.resblocks.2.attn.in_proj_weight",
+           "text_encoder.transformer.resblocks.0.attn.in_proj_bias", "text_encoder.ln_final.bias"]
+
+
+def fx_train_ft(mclip, mmodel, mopt, mmetrics):
+    dims = synth.TINY
+    sd = synth.finetune_state(dims)
+    for mode in ("fp32", "aswritten"):
+        # larger lr than the defaults so 3 steps move the sampled weights measurably
+        model, cfg = build_reference_model(mclip, mmodel.BirdModel, dims, sd, mode, lr=2e-3, text_lr=1e-3, coef_lr=0.5)
+        opt = _prep_optimizer(mopt, model, cfg, t_total=10)
+        out = {}
+        P = dict(model.named_parameters())
+        for step in range(4):
+            ids, mask, vid, vf, idx = synth.finetune_batch(4, 4, 32, tag=f"train_ft.s{step}")
+            loss = model(ids, mask, vid, vf, idx, step + 1)
+            loss.backward()
+            tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad()
+            out[f"loss{step}"], out[f"gnorm{step}"] = loss, tn
+            for k in SAMPLED:
+                out[f"p{step}:{k}"] = P[k].data.reshape(-1)[:16]
+        save(f"train_ft_{mode}", **out)
+
+
+class _Recorder:
+    """Record torch.bernoulli / torch.randint draws made inside get_mlm_loss."""
+
+    def __init__(self):
+        self.draws = []
+
+    def __enter__(self):
+        self._b, self._r = torch.bernoulli, torch.randint
+
+        def bern(*a, **k):
+            o = self._b(*a, **k)
+            self.draws.append(o.clone())
+            return o
+
+        def rint(*a, **k):
+            o = self._r(*a, **k)
+            self.draws.append(o.clone())
+            return o
+
+        torch.bernoulli, torch.randint = bern, rint
+        return self
+
+    def __exit__(self, *exc):
+        torch.bernoulli, torch.randint = self._b, self._r
+
+
+def fx_moco(mclip, mmodel, mopt, mmetrics):
+    dims = synth.TINY
+    K, B, Fr = 16, 4, 4
+    sd = synth.pretrain_state(dims, K, Fr)
+    for mode in ("fp32", "aswritten"):
+        model, cfg = build_reference_model(mclip, mmodel.BirdPreTrainedModel, dims, sd, mode, contrast_num_negative=K,
+                                           max_frames=Fr, dataset="chvtt", lr=2e-3, text_lr=1e-3, coef_lr=0.5,
+                                           weight_decay=0.05)
+        opt = _prep_optimizer(mopt, model, cfg, t_total=10)
+        parts = {}
+        for nm in ("frame_self_loss", "frame_cross_loss", "calculate_mlm_loss"):
+            orig = getattr(model, nm)
+
+            def wrap(*a, _o=orig, _n=nm, **k):
+                r = _o(*a, **k)
+                parts[_n] = r.detach().clone()
+                return r
+            setattr(model, nm, wrap)
+        out = {"K": K, "B": B, "F": Fr}
+        torch.manual_seed(1234)
+        for step in range(5):
+            batch = synth.pretrain_batch(B, Fr, tag=f"moco.s{step}")
+            vid, vf, tg, gm, ti, tm = batch
+            with _Recorder() as rec:
+                loss = model(vid, vf, tg, gm, ti, tm, step + 1)
+            assert len(rec.draws) == 4, len(rec.draws)
+            out[f"mlm_masked{step}"], out[f"mlm_replaced{step}"], out[f"mlm_randsel{step}"], out[f"mlm_words{step}"] = \
+                [d.numpy().astype(np.int64) for d in rec.draws]
+            loss.backward()
+            tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad()
+            out[f"loss{step}"], out[f"gnorm{step}"] = loss, tn
+            out[f"fam{step}"], out[f"ftm{step}"], out[f"mlm{step}"] = parts["frame_self_loss"], parts["frame_cross_loss"], \
+                parts["calculate_mlm_loss"]
+            out[f"ptr{step}"] = model.queue_ptr.clone()
+            S = model.state_dict()
+            for k in ("visual_encoder_k.visual.conv1.weight", "text_encoder_k.text_projection",
+                      "visual_encoder_k.temporal_transformer.resblocks.0.mlp.c_fc.weight",
+                      "v_projector_k.linear_out.weight", "text_encoder_k.ln_final.weight",
+                      "v_projector.linear_hidden.2.running_mean", "v_projector.linear_hidden.2.running_var",
+                      "v_projector_k.linear_hidden.2.running_mean", "v_predictor.linear_hidden.2.running_var"):
+                out[f"s{step}:{k}"] = S[k].reshape(-1)[:16]
+            if step in (0, 3, 4):
+                for qn in ("queue_v_cross_ng", "queue_title_cross_ng", "queue_tag_cross_ng", "queue_frame_proj_ng",
+                           "queue_frame_cross_ng"):
+                    out[f"q{step}:{qn}"] = S[qn][:32]   # first 32 of 512 feature rows, all columns
+        save(f"moco_{mode}", **out)
+
+
+FIXTURES = {"head": fx_head, "enc_tiny": fx_enc_tiny, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
+            "bertadam": fx_bertadam, "train_ft": fx_train_ft, "moco": fx_moco}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    mods = import_reference()
+    for name, fn in FIXTURES.items():
+        if args.only and name != args.only:
+            continue
+        print(f"== {name}")
+        fn(*mods)
+
+
+if __name__ == "__main__":
+    main()
