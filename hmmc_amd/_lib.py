@@ -1,0 +1,76 @@
+"""ctypes binding of libhmmc_hip.so — the C-ABI declared in include/hmmc_hip.h.
+
+The product path has no CPU fallback: if the library is missing, `load()` raises.
+PyTorch only supplies device memory (tensor.data_ptr()) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmmc_hip.so")
+
+_C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "z": ctypes.c_size_t}
+
+# name -> (argument codes, return code); must match include/hmmc_hip.h
+SIGNATURES = {
+    "hmmc_gemm_f16_workspace": ("iii", "z"),
+    "hmmc_gemm_f16": ("pppiiiiiiiippppipzp", "i"),
+    "hmmc_layernorm_fwd": ("pppppppiilfip", "i"),
+    "hmmc_layernorm_bwd_workspace": ("ii", "z"),
+    "hmmc_layernorm_bwd": ("ppppppppppiilipzp", "i"),
+    "hmmc_colsum_workspace": ("ii", "z"),
+    "hmmc_colsum": ("ppiiliiipzp", "i"),
+    "hmmc_patchify": ("ppiiiip", "i"),
+    "hmmc_vit_embed": ("pppliip", "i"),
+    "hmmc_text_embed": ("ppppliip", "i"),
+    "hmmc_text_embed_bwd": ("ppplip", "i"),
+    "hmmc_cast": ("pplip", "i"),
+    "hmmc_attention_f16_fwd": ("pppiiiip", "i"),
+    "hmmc_attention_f16_bwd": ("pppppiiiip", "i"),
+}
+
+ERRORS = {-1: "invalid argument", -2: "unsupported shape/alignment", -3: "workspace too small", -4: "kernel launch failed"}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m hmmc_amd.build` (hipcc, gfx950). "
+                "hmmc_amd has no CPU or eager fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (args, ret) in SIGNATURES.items():
+            fn = getattr(lib, name)            # AttributeError here = header/library mismatch
+            fn.argtypes = [_C[c] for c in args]
+            fn.restype = _C[ret]
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    """Call an int-returning entry point on the current stream; raise on a non-zero status."""
+    rc = getattr(load(), name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {ERRORS.get(rc, rc)}")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

@@ -1,0 +1,58 @@
+// Shared device helpers for the HMMC gfx950 kernels.  CDNA4 only: 64-lane waves,
+// MFMA 16x16x32 f16, LDS-DMA buffer loads.  No portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+#define HMMC_OK 0
+#define HMMC_ERR_ARG (-1)
+#define HMMC_ERR_UNSUPPORTED (-2)
+#define HMMC_ERR_WORKSPACE (-3)
+#define HMMC_ERR_LAUNCH (-4)
+
+static inline int hmmc_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? HMMC_OK : HMMC_ERR_LAUNCH;
+}
+
+// kernels that ask for more than 64 KiB of dynamic LDS must opt in once
+static inline void hmmc_allow_lds(const void* kernel, int bytes) {
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// round-trip through fp16 (the reference rounds at every fp16 tensor op)
+__device__ __forceinline__ float r16(float x) { return (float)(half_t)x; }
+
+// QuickGELU evaluated with the reference's fp16 rounding points
+// (modules/module_clip.py:226-228: x * sigmoid(1.702 * x) on an fp16 tensor).
+__device__ __forceinline__ float qgelu_f16(float h) {
+  float t = r16(1.702f * h);
+  float s = r16(1.0f / (1.0f + __expf(-t)));
+  return r16(h * s);
+}
+// d/dh [h * sigmoid(1.702 h)]
+__device__ __forceinline__ float qgelu_grad(float h) {
+  float s = 1.0f / (1.0f + __expf(-1.702f * h));
+  return s * (1.0f + 1.702f * h * (1.0f - s));
+}

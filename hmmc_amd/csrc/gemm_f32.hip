@@ -1,0 +1,172 @@
+// fp32 MFMA GEMM (exact f32 FMA chain, v_mfma_f32_16x16x4_f32) for the fp32 side of the hot path:
+// the temporal transformer (reference modules/module_cross.py:114-149,193-207), the similarity
+// matrices of loose_similarity / contrastive_loss (modules/modeling.py:207-229,286-313), the MoCo
+// projector MLPs (:788-807) and the MLM head (modules/module_cross.py:308-357).
+//
+//   C[m][n] = epilogue( alpha * sum_k A(m,k) * B(k,n) ),   A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+//
+// One of each operand's strides must be 1 (either orientation is read with 16-byte loads), so
+// x W^T, dy W, dy^T x, q K^T and q queue all go through the same kernel with no transposed copy.
+// 64x64x16 block tile, 4 waves (2x2, 32x32 each), register-staged double buffering; MFMA operands
+// swapped (A-operand = B rows) so a lane owns 4 consecutive n of one row: 16-byte stores.
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16;
+constexpr int LDS_LD = 80;   // floats per k-row: 64 + 16 keeps the two k-rows of a 32-lane half on disjoint banks
+
+enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_RELU = 16 };
+
+struct G32 {
+  const float* A; const float* B; float* C; const float* bias; const float* resid; float* aux_out; const float* aux_in;
+  int M, N, K; long sam, sak, sbk, sbn; int ldc; float alpha; int flags;
+};
+
+__device__ __forceinline__ float qgelu32(float h) { return h / (1.0f + __expf(-1.702f * h)); }
+
+// load this thread's 4 elements of a 64 x 16 operand tile (rows r0.., k-range k0..) into regs
+__device__ __forceinline__ f4 load_op(const float* P, long sr, long sk, int R, int K, int r0, int k0, int tid) {
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  if (sk == 1) {            // k contiguous: thread -> (row = tid/4, k = 4*(tid%4))
+    int r = r0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+    if (r < R) {
+      const float* p = P + (long)r * sr + k;
+      if (k + 3 < K) v = *reinterpret_cast<const f4*>(p);
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (k + j < K) v[j] = p[j];
+      }
+    }
+  } else {                  // row contiguous: thread -> (k = tid/16, row = 4*(tid%16))
+    int k = k0 + (tid >> 4), r = r0 + (tid & 15) * 4;
+    if (k < K) {
+      const float* p = P + (long)k * sk + r;
+      if (r + 3 < R) v = *reinterpret_cast<const f4*>(p);
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (r + j < R) v[j] = p[j];
+      }
+    }
+  }
+  return v;
+}
+
+// write them into the LDS image [k][row]
+__device__ __forceinline__ void store_op(float* S, f4 v, bool kcontig, int tid) {
+  if (kcontig) {
+    int r = tid >> 2, k = (tid & 3) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) S[(k + j) * LDS_LD + r] = v[j];
+  } else {
+    int k = tid >> 4, r = (tid & 15) * 4;
+    *reinterpret_cast<f4*>(S + k * LDS_LD + r) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
+  __shared__ __attribute__((aligned(16))) float sA[2][TK * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float sB[2][TK * LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int ntn = (p.N + TN - 1) / TN;
+  const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const bool ak = p.sak == 1, bk = p.sbk == 1;
+
+  f4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (p.K + TK - 1) / TK;
+  f4 ra = load_op(p.A, p.sam, p.sak, p.M, p.K, m0, 0, tid);
+  f4 rb = load_op(p.B, p.sbn, p.sbk, p.N, p.K, n0, 0, tid);
+  store_op(sA[0], ra, ak, tid);
+  store_op(sB[0], rb, bk, tid);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) {
+      ra = load_op(p.A, p.sam, p.sak, p.M, p.K, m0, (kt + 1) * TK, tid);
+      rb = load_op(p.B, p.sbn, p.sbk, p.N, p.K, n0, (kt + 1) * TK, tid);
+    }
+    const float* a = sA[cur];
+    const float* b = sB[cur];
+#pragma unroll
+    for (int kk = 0; kk < TK; kk += 4) {
+      float af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = a[(kk + (lane >> 4)) * LDS_LD + wm * 32 + i * 16 + (lane & 15)];
+        bf[i] = b[(kk + (lane >> 4)) * LDS_LD + wn * 32 + i * 16 + (lane & 15)];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) {
+      store_op(sA[cur ^ 1], ra, ak, tid);
+      store_op(sB[cur ^ 1], rb, bk, tid);
+    }
+    __syncthreads();
+  }
+  // lane owns C[m = .. + (lane & 15)][n = .. + 4*(lane >> 4) + r]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + wm * 32 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int n = n0 + wn * 32 + j * 16 + 4 * (lane >> 4);
+      if (n >= p.N) continue;
+      f4 v = acc[i][j];
+      long off = (long)m * p.ldc + n;
+      bool full = n + 3 < p.N;
+      float o[4], hsave[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = v[r] * p.alpha;
+        if ((p.flags & EPI_BIAS) && n + r < p.N) t += p.bias[n + r];
+        hsave[r] = t;
+        if (p.flags & EPI_QGELU) t = qgelu32(t);
+        else if (p.flags & EPI_RELU) t = fmaxf(t, 0.f);
+        else if ((p.flags & EPI_DGELU) && n + r < p.N) t *= qgelu_grad(p.aux_in[off + r]);
+        if ((p.flags & EPI_RESID) && n + r < p.N) t += p.resid[off + r];
+        o[r] = t;
+      }
+      if (full) {
+        *reinterpret_cast<f4*>(p.C + off) = f4{o[0], o[1], o[2], o[3]};
+        if (p.aux_out) *reinterpret_cast<f4*>(p.aux_out + off) = f4{hsave[0], hsave[1], hsave[2], hsave[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) { p.C[off + r] = o[r]; if (p.aux_out) p.aux_out[off + r] = hsave[r]; }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk,
+                             long sbn, int ldc, float alpha, const float* bias, const float* resid, float* aux_out,
+                             const float* aux_in, int epilogue, hipStream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return HMMC_ERR_ARG;
+  if ((sak != 1 && sam != 1) || (sbk != 1 && sbn != 1)) return HMMC_ERR_UNSUPPORTED;
+  long a_ld = sak == 1 ? sam : sak, b_ld = sbk == 1 ? sbn : sbk;
+  if ((a_ld & 3) || (b_ld & 3) || (ldc & 3)) return HMMC_ERR_UNSUPPORTED;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return HMMC_ERR_UNSUPPORTED;
+  if ((epilogue & EPI_BIAS) && !bias) return HMMC_ERR_ARG;
+  if ((epilogue & EPI_RESID) && !resid) return HMMC_ERR_ARG;
+  if ((epilogue & EPI_DGELU) && !aux_in) return HMMC_ERR_ARG;
+  G32 p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.resid = resid; p.aux_out = aux_out; p.aux_in = aux_in;
+  p.M = M; p.N = N; p.K = K; p.sam = sam; p.sak = sak; p.sbk = sbk; p.sbn = sbn; p.ldc = ldc; p.alpha = alpha;
+  p.flags = epilogue;
+  long blocks = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  return hmmc_launch_status();
+}

@@ -1,0 +1,429 @@
+// HBM-bound row kernels of the HMMC towers: LayerNorm forward/backward (K2), column sums
+// (bias / positional-embedding gradients), patch extraction feeding the patch-embed GEMM (K1),
+// CLS/positional add, token-embedding gather and its scatter-add backward.
+// Reference: modules/module_clip.py:217-223 (LayerNorm, fp32 math on fp16 tensors),
+// modules/until_module.py:54-67 (TF-style LN of the temporal blocks), modules/module_clip.py:307-313
+// (conv1 patchify, class token, positional embedding), modules/module_cross.py:287-291 (token embedding).
+// Every kernel moves 16 bytes per lane per access and keeps fp32 statistics in registers.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Vec;
+template <> struct Vec<half_t> { static constexpr int N = 8; typedef h8 type; };
+template <> struct Vec<float> { static constexpr int N = 4; typedef f4 type; };
+
+constexpr int LN_MAXD = 1024;  // widest LayerNorm row (ViT-B: 768, text/temporal: 512)
+
+// ---- LayerNorm forward: one wave per row ------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     const int* __restrict__ row_index, int rows, int D,
+                                                     long in_stride, float eps) {
+  constexpr int VN = Vec<T>::N;
+  constexpr int LN_MAXV = LN_MAXD / 64 / VN;
+  typedef typename Vec<T>::type V;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long src_row = row_index ? (long)row_index[row] : (long)row;
+  const T* xr = x + src_row * in_stride;
+  const int nchunk = D / VN;
+  float v[LN_MAXV][VN];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c = lane + 64 * i;
+    if (c < nchunk) {
+      V t = *reinterpret_cast<const V*>(xr + c * VN);
+#pragma unroll
+      for (int j = 0; j < VN; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) { float d = v[i][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  T* yr = y + (long)row * D;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    int c = lane + 64 * i;
+    if (c < nchunk) {
+      V o;
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        int col = c * VN + j;
+        o[j] = (T)((v[i][j] - mean) * rstd * gamma[col] + beta[col]);
+      }
+      *reinterpret_cast<V*>(yr + c * VN) = o;
+    }
+  }
+}
+
+// ---- LayerNorm backward: dx (+ optional residual grad), per-block partial dgamma/dbeta ---------
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.
+// Rows are read through the same optional row_index / in_stride as the forward; dx rows are
+// written to dx + dst_row * out_stride where dst_row = row_index ? row_index[row] : row.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ partial,
+                                                     const int* __restrict__ row_index, int rows, int D,
+                                                     long in_stride) {
+  constexpr int VN = Vec<T>::N;
+  constexpr int LN_MAXV = LN_MAXD / 64 / VN;
+  typedef typename Vec<T>::type V;
+  __shared__ float sred[4 * LN_MAXD];   // one stripe per wave
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nchunk = D / VN;
+  float dg[LN_MAXV][VN], db[LN_MAXV][VN];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+    for (int j = 0; j < VN; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+
+  for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+    const long src_row = row_index ? (long)row_index[row] : (long)row;
+    const T* xr = x + src_row * in_stride;
+    const T* dyr = dy + (long)row * D;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[LN_MAXV][VN], g[LN_MAXV][VN];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int c = lane + 64 * i;
+      if (c < nchunk) {
+        V tx = *reinterpret_cast<const V*>(xr + c * VN);
+        V td = *reinterpret_cast<const V*>(dyr + c * VN);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          float d = (float)td[j];
+          xh[i][j] = ((float)tx[j] - mean) * rstd;
+          g[i][j] = d * gamma[c * VN + j];
+          s1 += g[i][j];
+          s2 += g[i][j] * xh[i][j];
+          dg[i][j] += d * xh[i][j];
+          db[i][j] += d;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / D;
+    s2 = wave_sum(s2) / D;
+    T* dxr = dx + src_row * in_stride;
+    const T* drr = dres ? dres + src_row * in_stride : nullptr;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int c = lane + 64 * i;
+      if (c < nchunk) {
+        V o;
+        V rr;
+        if (drr) rr = *reinterpret_cast<const V*>(drr + c * VN);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          float val = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+          if (drr) val += (float)rr[j];
+          o[j] = (T)val;
+        }
+        *reinterpret_cast<V*>(dxr + c * VN) = o;
+      }
+    }
+  }
+  // combine the 4 waves of the block, then one partial row per block: partial[block][0|1][D]
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      int c = lane + 64 * i;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) sred[w * LN_MAXD + c * VN + j] = pass ? db[i][j] : dg[i][j];
+      }
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < D; col += 256) {
+      float t = sred[col] + sred[LN_MAXD + col] + sred[2 * LN_MAXD + col] + sred[3 * LN_MAXD + col];
+      partial[((long)blockIdx.x * 2 + pass) * D + col] = t;
+    }
+  }
+}
+
+// out[col] = sum_b partial[b][which][col]
+__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int nblocks, int D) {
+  int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= D) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nblocks; ++k) {
+    a += partial[((long)k * 2) * D + col];
+    b += partial[((long)k * 2 + 1) * D + col];
+  }
+  dgamma[col] = a;
+  dbeta[col] = b;
+}
+
+// ---- column sums: out[n] = sum_m X[m][n]  (two stages, fp32 partials) ---------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, float* __restrict__ partial,
+                                                             int M, int N, long ld, int rows_per_block) {
+  constexpr int VN = Vec<T>::N;
+  typedef typename Vec<T>::type V;
+  // blockIdx.x: column group of 256 chunks; blockIdx.y: row block
+  const int chunk = blockIdx.x * 256 + threadIdx.x;
+  const int col = chunk * VN;
+  if (col >= N) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float acc[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) acc[j] = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    V t = *reinterpret_cast<const V*>(X + (long)r * ld + col);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) acc[j] += (float)t[j];
+  }
+#pragma unroll
+  for (int j = 0; j < VN; ++j) partial[(long)blockIdx.y * N + col + j] = acc[j];
+}
+
+template <typename TO>
+__global__ void colsum_final_kernel(const float* __restrict__ partial, TO* __restrict__ out, int nblocks, int N,
+                                    int round_f16) {
+  int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float a = 0.f;
+  for (int k = 0; k < nblocks; ++k) a += partial[(long)k * N + col];
+  if (round_f16) a = r16(a);
+  out[col] = (TO)a;
+}
+
+// ---- patch extraction (im2col of the stride=patch conv), fp32 NCHW -> fp16 [N*L, 3*p*p] ---------
+// Row n*L + 0 is a zero row (class-token slot); row n*L + 1 + gy*g + gx is patch (gy, gx),
+// columns ordered (c, ky, kx) like conv1.weight[width, 3, p, p].
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, half_t* __restrict__ out,
+                                                       int nframes, int H, int W, int p, int g) {
+  const int L = g * g + 1;
+  const int kc = 3 * p * p / 8;                 // 16-byte chunks per output row
+  const long total = (long)nframes * L * kc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int ch = (int)(idx % kc);
+    long row = idx / kc;
+    int l = (int)(row % L);
+    long n = row / L;
+    h8 o;
+    if (l == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)0.f;
+    } else {
+      int gy = (l - 1) / g, gx = (l - 1) % g;
+      int per_c = p * p / 8;
+      int c = ch / per_c, rem = ch % per_c;
+      int ky = rem / (p / 8), kx = (rem % (p / 8)) * 8;
+      const float* src = img + (((n * 3 + c) * H + gy * p + ky) * (long)W + gx * p + kx);
+      f4 a = *reinterpret_cast<const f4*>(src);
+      f4 b = *reinterpret_cast<const f4*>(src + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j] = (half_t)a[j]; o[4 + j] = (half_t)b[j]; }
+    }
+    *reinterpret_cast<h8*>(out + idx * 8) = o;
+  }
+}
+
+// x[n][l][:] = fp16( x[n][l][:] + (l == 0 ? fp16(cls) : 0) ) then fp16( . + fp16(pos[l]) )   (in place)
+__global__ __launch_bounds__(256) void vit_embed_kernel(half_t* __restrict__ x, const float* __restrict__ cls,
+                                                        const float* __restrict__ pos, long rows, int L, int D) {
+  const int dc = D / 8;
+  const long total = rows * dc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int c = (int)(idx % dc);
+    long row = idx / dc;
+    int l = (int)(row % L);
+    h8 v = *reinterpret_cast<h8*>(x + idx * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = (float)v[j];
+      if (l == 0) t = r16(cls[c * 8 + j]);              // conv output of the zero row is 0
+      t = r16(t + r16(pos[l * D + c * 8 + j]));
+      v[j] = (half_t)t;
+    }
+    *reinterpret_cast<h8*>(x + idx * 8) = v;
+  }
+}
+
+// x[b][l][:] = fp16( fp16(table[ids[b][l]][:]) + fp16(pos[l][:]) )
+__global__ __launch_bounds__(256) void text_embed_kernel(const long* __restrict__ ids, const float* __restrict__ table,
+                                                         const float* __restrict__ pos, half_t* __restrict__ x,
+                                                         long rows, int L, int D) {
+  const int dc = D / 8;
+  const long total = rows * dc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int c = (int)(idx % dc);
+    long row = idx / dc;
+    int l = (int)(row % L);
+    const float* tr = table + ids[row] * (long)D + c * 8;
+    const float* pr = pos + (long)l * D + c * 8;
+    f4 a = *reinterpret_cast<const f4*>(tr), b = *reinterpret_cast<const f4*>(tr + 4);
+    f4 pa = *reinterpret_cast<const f4*>(pr), pb = *reinterpret_cast<const f4*>(pr + 4);
+    h8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = (half_t)(r16(a[j]) + r16(pa[j]));
+      o[4 + j] = (half_t)(r16(b[j]) + r16(pb[j]));
+    }
+    *reinterpret_cast<h8*>(x + idx * 8) = o;
+  }
+}
+
+// dtable[ids[row]][:] += dx[row][:]   (fp32 table gradient, dense, zeroed by the caller)
+__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const long* __restrict__ ids, const half_t* __restrict__ dx,
+                                                             float* __restrict__ dtable, long rows, int D) {
+  const long total = rows * D;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long row = idx / D;
+    int d = (int)(idx - row * D);
+    atomicAdd(dtable + ids[row] * (long)D + d, (float)dx[idx]);
+  }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = (TO)in[i];
+}
+
+inline int grid_for(long work_items, int block = 256, int cap = 2048) {
+  long b = (work_items + block - 1) / block;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+// dtype: 0 = fp16 I/O (CLIP towers), 1 = fp32 I/O (temporal transformer, MLM head)
+extern "C" int hmmc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                  const int* row_index, int rows, int D, long in_stride, float eps, int dtype,
+                                  hipStream_t stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return HMMC_ERR_ARG;
+  int vn = dtype == 0 ? 8 : 4;
+  if (D % vn || D > LN_MAXD || in_stride % vn) return HMMC_ERR_UNSUPPORTED;
+  dim3 grid((rows + 3) / 4), block(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(ln_fwd_kernel<half_t>, grid, block, 0, stream, (const half_t*)x, gamma, beta, (half_t*)y, mean, rstd,
+                       row_index, rows, D, in_stride, eps);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, stream, (const float*)x, gamma, beta, (float*)y, mean, rstd,
+                       row_index, rows, D, in_stride, eps);
+  return hmmc_launch_status();
+}
+
+extern "C" size_t hmmc_layernorm_bwd_workspace(int rows, int D) {
+  int nb = (rows + 3) / 4;
+  if (nb > 512) nb = 512;
+  return (size_t)nb * 2 * D * sizeof(float);
+}
+
+// dx rows are written at the same (row_index, in_stride) positions the forward read x from.
+extern "C" int hmmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                  const void* dres, void* dx, float* dgamma, float* dbeta, const int* row_index, int rows,
+                                  int D, long in_stride, int dtype, void* workspace, size_t ws_bytes, hipStream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return HMMC_ERR_ARG;
+  int vn = dtype == 0 ? 8 : 4;
+  if (D % vn || D > LN_MAXD || in_stride % vn) return HMMC_ERR_UNSUPPORTED;
+  int nb = (rows + 3) / 4;
+  if (nb > 512) nb = 512;
+  if (!workspace || ws_bytes < (size_t)nb * 2 * D * sizeof(float)) return HMMC_ERR_WORKSPACE;
+  float* partial = (float*)workspace;
+  if (dtype == 0)
+    hipLaunchKernelGGL(ln_bwd_kernel<half_t>, dim3(nb), dim3(256), 0, stream, (const half_t*)dy, (const half_t*)x, gamma,
+                       mean, rstd, (const half_t*)dres, (half_t*)dx, partial, row_index, rows, D, in_stride);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)dy, (const float*)x, gamma, mean,
+                       rstd, (const float*)dres, (float*)dx, partial, row_index, rows, D, in_stride);
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)partial, dgamma,
+                     dbeta, nb, D);
+  return hmmc_launch_status();
+}
+
+extern "C" size_t hmmc_colsum_workspace(int M, int N) {
+  int rb = (M + 255) / 256;
+  if (rb > 256) rb = 256;
+  return (size_t)rb * N * sizeof(float);
+}
+
+// out[n] = sum_m X[m][n]; in_dtype/out_dtype: 0 fp16, 1 fp32; round_f16: round the fp32 sum to fp16 first
+extern "C" int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int in_dtype, int out_dtype, int round_f16,
+                           void* workspace, size_t ws_bytes, hipStream_t stream) {
+  if (!X || !out || M <= 0 || N <= 0) return HMMC_ERR_ARG;
+  int vn = in_dtype == 0 ? 8 : 4;
+  if (N % vn || ld % vn) return HMMC_ERR_UNSUPPORTED;
+  int rb = (M + 255) / 256;
+  if (rb > 256) rb = 256;
+  int rpb = (M + rb - 1) / rb;
+  rb = (M + rpb - 1) / rpb;
+  if (!workspace || ws_bytes < (size_t)rb * N * sizeof(float)) return HMMC_ERR_WORKSPACE;
+  dim3 grid((N / vn + 255) / 256, rb);
+  if (in_dtype == 0)
+    hipLaunchKernelGGL(colsum_partial_kernel<half_t>, grid, dim3(256), 0, stream, (const half_t*)X, (float*)workspace, M, N,
+                       ld, rpb);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, (float*)workspace, M, N, ld,
+                       rpb);
+  if (out_dtype == 0)
+    hipLaunchKernelGGL(colsum_final_kernel<half_t>, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace,
+                       (half_t*)out, rb, N, round_f16);
+  else
+    hipLaunchKernelGGL(colsum_final_kernel<float>, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace,
+                       (float*)out, rb, N, round_f16);
+  return hmmc_launch_status();
+}
+
+extern "C" int hmmc_patchify(const float* img, void* out, int nframes, int H, int W, int patch, hipStream_t stream) {
+  if (!img || !out || nframes <= 0) return HMMC_ERR_ARG;
+  if (patch % 8 || H % patch || W % patch || H != W || (W & 3)) return HMMC_ERR_UNSUPPORTED;
+  int g = H / patch;
+  long total = (long)nframes * (g * g + 1) * (3 * patch * patch / 8);
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, img, (half_t*)out, nframes, H, W,
+                     patch, g);
+  return hmmc_launch_status();
+}
+
+extern "C" int hmmc_vit_embed(void* x, const float* cls, const float* pos, long rows, int L, int D, hipStream_t stream) {
+  if (!x || !cls || !pos || rows <= 0 || D % 8) return HMMC_ERR_ARG;
+  hipLaunchKernelGGL(vit_embed_kernel, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, (half_t*)x, cls, pos,
+                     rows, L, D);
+  return hmmc_launch_status();
+}
+
+extern "C" int hmmc_text_embed(const long* ids, const float* table, const float* pos, void* x, long rows, int L, int D,
+                               hipStream_t stream) {
+  if (!ids || !table || !pos || !x || rows <= 0 || D % 8) return HMMC_ERR_ARG;
+  hipLaunchKernelGGL(text_embed_kernel, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, ids, table, pos,
+                     (half_t*)x, rows, L, D);
+  return hmmc_launch_status();
+}
+
+extern "C" int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, hipStream_t stream) {
+  if (!ids || !dx || !dtable || rows <= 0) return HMMC_ERR_ARG;
+  hipLaunchKernelGGL(text_embed_bwd_kernel, dim3(grid_for(rows * D, 256, 4096)), dim3(256), 0, stream, ids,
+                     (const half_t*)dx, dtable, rows, D);
+  return hmmc_launch_status();
+}
+
+// kind: 0 = fp16 -> fp32, 1 = fp32 -> fp16
+extern "C" int hmmc_cast(const void* in, void* out, long n, int kind, hipStream_t stream) {
+  if (!in || !out || n <= 0) return HMMC_ERR_ARG;
+  if (kind == 0)
+    hipLaunchKernelGGL((cast_kernel<half_t, float>), dim3(grid_for(n)), dim3(256), 0, stream, (const half_t*)in, (float*)out, n);
+  else
+    hipLaunchKernelGGL((cast_kernel<float, half_t>), dim3(grid_for(n)), dim3(256), 0, stream, (const float*)in, (half_t*)out, n);
+  return hmmc_launch_status();
+}

@@ -1,0 +1,95 @@
+/* hmmc_hip.h — C-ABI of libhmmc_hip.so, the MI355X (gfx950) kernels behind the HMMC training
+ * hot path.  The reference (cheetah003/HMMC) has no FFI boundary of its own: its hot path sits
+ * behind torch nn.Module / Optimizer objects.  Each entry point below therefore names the
+ * reference op sequence (file:line under the reference checkout) whose device work it replaces;
+ * the Python classes in hmmc_amd/ that mirror the reference's module API call these through
+ * ctypes (hmmc_amd/_lib.py), and INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions: plain device pointers and sizes; the caller owns every buffer (outputs and
+ * workspaces are pre-allocated; hmmc_*_workspace() returns the bytes an op needs); kernels are
+ * enqueued on `stream` (a hipStream_t) and never synchronise or allocate; no global mutable
+ * state.  Return value: 0 on success, HMMC_ERR_* (< 0) otherwise — nothing is launched on error.
+ * fp16 buffers are IEEE binary16; "tokens" are rows of a row-major [tokens, D] matrix with each
+ * sequence's L tokens contiguous.
+ */
+#ifndef HMMC_HIP_H
+#define HMMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hmmc_stream_t; /* hipStream_t */
+
+#define HMMC_OK 0
+#define HMMC_ERR_ARG (-1)
+#define HMMC_ERR_UNSUPPORTED (-2)
+#define HMMC_ERR_WORKSPACE (-3)
+#define HMMC_ERR_LAUNCH (-4)
+
+/* epilogue flags of hmmc_gemm_f16 */
+#define HMMC_EPI_BIAS 1  /* + bias[n]                                   */
+#define HMMC_EPI_RESID 2 /* out = fp16(resid + fp16(acc + bias))        */
+#define HMMC_EPI_QGELU 4 /* out = QuickGELU(h), aux_out = h = fp16(acc + bias) */
+#define HMMC_EPI_DGELU 8 /* out = acc * QuickGELU'(aux_in)              */
+
+/* fp16 MFMA GEMM, fp32 accumulate: C[M,N] = epilogue(sum_k Aop[m][k] * Bop[n][k]).
+ * a_kmajor: Aop[m][k] = A[m*lda + k], else A[k*lda + m]; likewise b_kmajor for B (rows n).
+ * Replaces F.linear / nn.MultiheadAttention in/out projections and the MLP of
+ * ResidualAttentionBlock (modules/module_clip.py:231-257), the patch conv1 (:278,307), the
+ * ln_post/ln_final projections (modules/module_cross.py:228,296) and all their backward GEMMs.
+ * Without an epilogue, small-output/long-K problems (weight gradients) are split over K into
+ * fp32 slabs in `workspace` (hmmc_gemm_f16_workspace bytes; may be NULL to disable). */
+size_t hmmc_gemm_f16_workspace(int M, int N, int K);
+int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor,
+                  int b_kmajor, const void* bias, const void* resid, void* aux_out, const void* aux_in, int epilogue,
+                  void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+
+/* LayerNorm over the last dim (fp32 statistics).  dtype 0: fp16 in/out (CLIP LayerNorm,
+ * modules/module_clip.py:217-223, eps 1e-5); dtype 1: fp32 (TF-style LN of the temporal blocks and
+ * MLM head, modules/until_module.py:54-67, eps 1e-12).  Output row r reads input row
+ * (row_index ? row_index[r] : r) at stride in_stride — used to normalise only the CLS / EOT rows
+ * (modules/module_cross.py:228-230,296-300).  mean/rstd [rows] are saved for the backward. */
+int hmmc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                       const int* row_index, int rows, int D, long in_stride, float eps, int dtype, hmmc_stream_t stream);
+size_t hmmc_layernorm_bwd_workspace(int rows, int D);
+/* dx[row] = LN'(dy)[row] + (dres ? dres[row] : 0), written at the rows the forward read. */
+int hmmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       const void* dres, void* dx, float* dgamma, float* dbeta, const int* row_index, int rows, int D,
+                       long in_stride, int dtype, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+
+/* out[n] = sum_m X[m][n] (bias, class/positional-embedding gradients). dtypes: 0 fp16, 1 fp32. */
+size_t hmmc_colsum_workspace(int M, int N);
+int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int in_dtype, int out_dtype, int round_f16,
+                void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+
+/* Patch extraction for conv1 (kernel = stride = patch, modules/module_clip.py:278,307-310):
+ * fp32 NCHW frames -> fp16 [nframes*(g*g+1), 3*patch*patch]; row 0 of each frame is zero (class slot). */
+int hmmc_patchify(const float* img, void* out, int nframes, int H, int W, int patch, hmmc_stream_t stream);
+/* In place on the patch-GEMM output: class_embedding into row 0, + positional_embedding
+ * (modules/module_clip.py:311-312), with the reference's fp16 rounding points. */
+int hmmc_vit_embed(void* x, const float* cls, const float* pos, long rows, int L, int D, hmmc_stream_t stream);
+/* token_embedding(ids).half() + positional_embedding[:L].half() (modules/module_cross.py:288-291). */
+int hmmc_text_embed(const long* ids, const float* table, const float* pos, void* x, long rows, int L, int D,
+                    hmmc_stream_t stream);
+/* dense fp32 embedding gradient: dtable[ids[r]] += dx[r] (dtable zeroed by the caller). */
+int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, hmmc_stream_t stream);
+/* kind 0: fp16 -> fp32, 1: fp32 -> fp16 */
+int hmmc_cast(const void* in, void* out, long n, int kind, hmmc_stream_t stream);
+
+/* Fused softmax(QK^T/8 + mask)V per (sequence, head), head dim 64, L <= 64.  qkv: [nseq*L, 3*64*H]
+ * packed in-projection output; out: [nseq*L, 64*H]; lse: [nseq, H, L] log-sum-exp rows (saved for
+ * backward).  causal != 0 applies CLIP's text mask (modules/module_clip.py:441-447).
+ * Replaces the attention core of nn.MultiheadAttention at modules/module_clip.py:251. */
+int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, int nseq, int L, int H, int causal,
+                           hmmc_stream_t stream);
+int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, int nseq,
+                           int L, int H, int causal, hmmc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMMC_HIP_H */

@@ -1,0 +1,186 @@
+"""GPU unit tests of the individual HIP kernels through the C-ABI, each against a plain PyTorch
+fp32 reference of the same op (bit-exact on integer-valued data where the op is exact)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hmmc_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, dtype=torch.float16, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def ints(*shape, lo=-2, hi=3, dtype=torch.float16, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return torch.randint(lo, hi, shape, generator=g).to(dtype).to(DEV)
+
+
+def relerr(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
+# ----------------------------------------------------------------------------- GEMM
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (800, 384, 128), (130, 136, 192), (2048, 768, 768)])
+def test_gemm_kk_exact_integers(M, N, K):
+    a, b = ints(M, K), ints(N, K, seed=1)
+    c = ops.gemm_f16(a, b, M, N, K)
+    ref = a.float() @ b.float().t()
+    assert torch.equal(c.float(), ref), f"max diff {(c.float()-ref).abs().max()}"
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (800, 384, 200), (1000, 512, 136), (4096, 768, 2304)])
+def test_gemm_km_dgrad_exact_integers(M, N, K):
+    # dx[M,N] = dy[M,K] @ W[K,N]  (A k-major, B m-major: Bop[n][k] = W[k][n])
+    dy, w = ints(M, K), ints(K, N, seed=1)
+    if K % 64:
+        pytest.skip("k-major operand needs K % 64 == 0")
+    c = ops.gemm_f16(dy, w, M, N, K, a_kmajor=True, b_kmajor=False)
+    ref = dy.float() @ w.float()
+    assert torch.equal(c.float(), ref), f"max diff {(c.float()-ref).abs().max()}"
+
+
+@pytest.mark.parametrize("T,N,K", [(64, 128, 128), (800, 384, 128), (1000, 136, 264), (12800, 768, 384)])
+def test_gemm_mm_wgrad_exact_integers(T, N, K):
+    # dW[N,K] = dy[T,N]^T @ x[T,K]   (both m-major, reduction over T incl. ragged tail and split-K)
+    dy, x = ints(T, N, lo=-1, hi=2), ints(T, K, lo=-1, hi=2, seed=1)
+    c = ops.gemm_f16(dy, x, N, K, T, a_kmajor=False, b_kmajor=False)
+    ref = dy.float().t() @ x.float()
+    assert float(ref.abs().max()) <= 2048
+    assert torch.equal(c.float(), ref), f"max diff {(c.float()-ref).abs().max()}"
+
+
+def test_gemm_random_and_epilogues():
+    M, N, K = 1000, 384, 256
+    a, w = rnd(M, K, scale=0.5), rnd(N, K, scale=0.1, seed=1)
+    bias, res = rnd(N, scale=0.1, seed=2), rnd(M, N, seed=3)
+    acc = a.float() @ w.float().t()
+    c = ops.gemm_f16(a, w, M, N, K, bias=bias)
+    assert relerr(c, acc + bias.float()) < 2e-3
+    c = ops.gemm_f16(a, w, M, N, K, bias=bias, resid=res, epilogue=ops.EPI_RESID)
+    ref = (res.float() + (acc + bias.float()).half().float()).half()
+    assert relerr(c, ref) < 1e-3 and float((c.float() - ref.float()).abs().max()) < 2e-2
+    g, h = ops.gemm_f16(a, w, M, N, K, bias=bias, epilogue=ops.EPI_QGELU, want_aux=True)
+    href = (acc + bias.float()).half()
+    assert relerr(h, href) < 1e-3
+    gref = h.float() * torch.sigmoid(1.702 * h.float())
+    assert relerr(g, gref) < 2e-3
+    dh = ops.gemm_f16(a, w, M, N, K, aux_in=h, epilogue=ops.EPI_DGELU)
+    s = torch.sigmoid(1.702 * h.float())
+    dref = acc * (s * (1 + 1.702 * h.float() * (1 - s)))
+    assert relerr(dh, dref) < 2e-3
+
+
+# ----------------------------------------------------------------------------- LayerNorm / rows
+
+@pytest.mark.parametrize("dtype,D,eps", [(torch.float16, 768, 1e-5), (torch.float16, 128, 1e-5), (torch.float32, 512, 1e-12)])
+def test_layernorm_fwd_bwd(dtype, D, eps):
+    rows = 1003
+    x = rnd(rows, D, dtype=dtype)
+    gamma = rnd(D, dtype=torch.float32, seed=1) * 0.1 + 1
+    beta = rnd(D, dtype=torch.float32, seed=2) * 0.1
+    dy, dres = rnd(rows, D, dtype=dtype, seed=3), rnd(rows, D, dtype=dtype, seed=4)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+    xr = x.float().requires_grad_()
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, eps)
+    tol = 2e-3 if dtype == torch.float16 else 1e-5
+    assert relerr(y, yr) < tol
+    yr.backward(dy.float())
+    dx, dg, db = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres=dres)
+    assert relerr(dx, xr.grad + dres.float()) < tol
+    assert relerr(dg, gr.grad) < 1e-4 and relerr(db, br.grad) < 1e-4
+
+
+def test_layernorm_row_gather():
+    n, L, D = 37, 50, 768
+    x = rnd(n * L, D)
+    gamma, beta = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    idx = (torch.arange(n, device=DEV, dtype=torch.int32) * L).contiguous()
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5, row_index=idx)
+    ref = torch.nn.functional.layer_norm(x.view(n, L, D)[:, 0].float(), (D,))
+    assert relerr(y, ref) < 2e-3
+    dy = rnd(n, D, seed=5)
+    dx = torch.zeros_like(x)
+    dx, dg, db = ops.layernorm_bwd(dy, x, gamma, mean, rstd, row_index=idx, dx=dx)
+    xr = x.view(n, L, D)[:, 0].float().requires_grad_()
+    torch.nn.functional.layer_norm(xr, (D,)).backward(dy.float())
+    assert relerr(dx.view(n, L, D)[:, 0], xr.grad) < 2e-3
+    assert float(dx.view(n, L, D)[:, 1:].abs().max()) == 0.0
+
+
+def test_colsum_patchify_embed():
+    x = rnd(1234, 768)
+    s = ops.colsum(x, out_dtype=torch.float32)
+    assert relerr(s, x.float().sum(0)) < 1e-5
+    xf = rnd(777, 512, dtype=torch.float32)
+    assert relerr(ops.colsum(xf), xf.sum(0)) < 1e-5
+    # patchify == unfold of the stride-p conv, (c, ky, kx) column order, zero class row
+    for p in (32, 16):
+        vid = rnd(3, 3, 224, 224, dtype=torch.float32)
+        out = ops.patchify(vid, p)
+        g = 224 // p
+        ref = torch.nn.functional.unfold(vid, kernel_size=p, stride=p).transpose(1, 2)     # [n, g*g, 3*p*p]
+        out = out.view(3, g * g + 1, -1)
+        assert torch.equal(out[:, 1:], ref.half())
+        assert float(out[:, 0].abs().max()) == 0.0
+    # vit_embed
+    L, D = 50, 768
+    t = rnd(4 * L, D)
+    t.view(4, L, D)[:, 0] = 0
+    cls, pos = rnd(D, dtype=torch.float32, seed=1), rnd(L, D, dtype=torch.float32, seed=2)
+    ref = t.clone().view(4, L, D)
+    ref[:, 0] = cls.half()
+    ref = (ref + pos.half()).view(4 * L, D)
+    got = ops.vit_embed_(t.clone(), cls, pos, L)
+    assert torch.equal(got, ref)
+    # text embed fwd / bwd
+    ids = torch.randint(0, 1000, (6, 32), device=DEV)
+    table, tpos = rnd(1000, 512, dtype=torch.float32, scale=0.02), rnd(77, 512, dtype=torch.float32, scale=0.01, seed=3)
+    xe = ops.text_embed(ids, table, tpos)
+    ref = (table[ids].half() + tpos[:32].half()).view(-1, 512)
+    assert torch.equal(xe, ref)
+    dx = rnd(6 * 32, 512, seed=9)
+    dt = ops.text_embed_bwd(ids, dx, 1000)
+    ref = torch.zeros(1000, 512, device=DEV).index_add_(0, ids.view(-1), dx.float())
+    assert relerr(dt, ref) < 1e-5
+
+
+# ----------------------------------------------------------------------------- attention
+
+def attn_ref(qkv, nseq, L, H, causal):
+    D = H * 64
+    q, k, v = qkv.float().view(nseq, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=qkv.device).triu_(1)
+    p = torch.softmax(s, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(nseq * L, D)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("nseq,L,H,causal", [(5, 50, 2, False), (3, 32, 8, True), (2, 45, 2, True), (7, 25, 2, True),
+                                             (4, 64, 12, False), (3, 17, 2, False)])
+def test_attention_fwd_bwd(nseq, L, H, causal):
+    D = H * 64
+    qkv = rnd(nseq * L, 3 * D, scale=1.0)
+    out, lse = ops.attention_f16_fwd(qkv, nseq, L, H, causal)
+    qr = qkv.float().requires_grad_()
+    oref, lref = attn_ref(qr, nseq, L, H, causal)
+    assert relerr(out, oref) < 3e-3, relerr(out, oref)
+    assert float((lse - lref).abs().max()) < 2e-3
+    dout = rnd(nseq * L, D, seed=11)
+    oref.backward(dout.float())
+    dqkv = ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal)
+    g = qr.grad.view(nseq * L, 3, D)
+    d = dqkv.view(nseq * L, 3, D)
+    for i, nm in enumerate("qkv"):
+        e = relerr(d[:, i], g[:, i])
+        assert e < 8e-3, f"d{nm} rel err {e}"
