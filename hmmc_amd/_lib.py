@@ -31,6 +31,23 @@ SIGNATURES = {
     "hmmc_cast": ("pplip", "i"),
     "hmmc_attention_f16_fwd": ("pppiiiip", "i"),
     "hmmc_attention_f16_bwd": ("pppppiiiip", "i"),
+    "hmmc_gemm_f32": ("pppiiillllifppppip", "i"),
+    "hmmc_l2norm_fwd": ("pppiifp", "i"),
+    "hmmc_l2norm_bwd": ("ppppiip", "i"),
+    "hmmc_infonce_fwd": ("ppppiiffp", "i"),
+    "hmmc_infonce_bwd": ("pppppiiffp", "i"),
+    "hmmc_topk_mean": ("pppiiiillp", "i"),
+    "hmmc_temporal_pool_fwd": ("ppppiiip", "i"),
+    "hmmc_temporal_pool_bwd": ("pppppiiip", "i"),
+    "hmmc_add_rowbias": ("pppliip", "i"),
+    "hmmc_temporal_attention_fwd": ("pppiiiip", "i"),
+    "hmmc_temporal_attention_bwd": ("ppppiiip", "i"),
+    "hmmc_mt_chunk_elems": ("", "i"),
+    "hmmc_mt_sumsq": ("ppipip", "i"),
+    "hmmc_mt_clip_grad_norm": ("ppipifpp", "i"),
+    "hmmc_mt_bertadam": ("pppipip", "i"),
+    "hmmc_mt_ema": ("ppiffp", "i"),
+    "hmmc_enqueue": ("ppiillp", "i"),
 }
 
 ERRORS = {-1: "invalid argument", -2: "unsupported shape/alignment", -3: "workspace too small", -4: "kernel launch failed"}

@@ -20,19 +20,19 @@ enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_RELU = 16 
 
 struct G32 {
   const float* A; const float* B; float* C; const float* bias; const float* resid; float* aux_out; const float* aux_in;
-  int M, N, K; long sam, sak, sbk, sbn; int ldc; float alpha; int flags;
+  int M, N, K; long sam, sak, sbk, sbn; int ldc; float alpha; int flags; int avec, bvec, cvec;
 };
 
 __device__ __forceinline__ float qgelu32(float h) { return h / (1.0f + __expf(-1.702f * h)); }
 
 // load this thread's 4 elements of a 64 x 16 operand tile (rows r0.., k-range k0..) into regs
-__device__ __forceinline__ f4 load_op(const float* P, long sr, long sk, int R, int K, int r0, int k0, int tid) {
+__device__ __forceinline__ f4 load_op(const float* P, long sr, long sk, int R, int K, int r0, int k0, int tid, bool vec) {
   f4 v = {0.f, 0.f, 0.f, 0.f};
   if (sk == 1) {            // k contiguous: thread -> (row = tid/4, k = 4*(tid%4))
     int r = r0 + (tid >> 2), k = k0 + (tid & 3) * 4;
     if (r < R) {
       const float* p = P + (long)r * sr + k;
-      if (k + 3 < K) v = *reinterpret_cast<const f4*>(p);
+      if (vec && k + 3 < K) v = *reinterpret_cast<const f4*>(p);
       else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (k + j < K) v[j] = p[j];
@@ -42,7 +42,7 @@ __device__ __forceinline__ f4 load_op(const float* P, long sr, long sk, int R, i
     int k = k0 + (tid >> 4), r = r0 + (tid & 15) * 4;
     if (k < K) {
       const float* p = P + (long)k * sk + r;
-      if (r + 3 < R) v = *reinterpret_cast<const f4*>(p);
+      if (vec && r + 3 < R) v = *reinterpret_cast<const f4*>(p);
       else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (r + j < R) v[j] = p[j];
@@ -81,16 +81,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
     for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (p.K + TK - 1) / TK;
-  f4 ra = load_op(p.A, p.sam, p.sak, p.M, p.K, m0, 0, tid);
-  f4 rb = load_op(p.B, p.sbn, p.sbk, p.N, p.K, n0, 0, tid);
+  f4 ra = load_op(p.A, p.sam, p.sak, p.M, p.K, m0, 0, tid, p.avec);
+  f4 rb = load_op(p.B, p.sbn, p.sbk, p.N, p.K, n0, 0, tid, p.bvec);
   store_op(sA[0], ra, ak, tid);
   store_op(sB[0], rb, bk, tid);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nkt) {
-      ra = load_op(p.A, p.sam, p.sak, p.M, p.K, m0, (kt + 1) * TK, tid);
-      rb = load_op(p.B, p.sbn, p.sbk, p.N, p.K, n0, (kt + 1) * TK, tid);
+      ra = load_op(p.A, p.sam, p.sak, p.M, p.K, m0, (kt + 1) * TK, tid, p.avec);
+      rb = load_op(p.B, p.sbn, p.sbk, p.N, p.K, n0, (kt + 1) * TK, tid, p.bvec);
     }
     const float* a = sA[cur];
     const float* b = sB[cur];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
       if (n >= p.N) continue;
       f4 v = acc[i][j];
       long off = (long)m * p.ldc + n;
-      bool full = n + 3 < p.N;
+      bool full = p.cvec && n + 3 < p.N;
       float o[4], hsave[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -157,8 +157,7 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return HMMC_ERR_ARG;
   if ((sak != 1 && sam != 1) || (sbk != 1 && sbn != 1)) return HMMC_ERR_UNSUPPORTED;
   long a_ld = sak == 1 ? sam : sak, b_ld = sbk == 1 ? sbn : sbk;
-  if ((a_ld & 3) || (b_ld & 3) || (ldc & 3)) return HMMC_ERR_UNSUPPORTED;
-  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return HMMC_ERR_UNSUPPORTED;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 3) return HMMC_ERR_UNSUPPORTED;
   if ((epilogue & EPI_BIAS) && !bias) return HMMC_ERR_ARG;
   if ((epilogue & EPI_RESID) && !resid) return HMMC_ERR_ARG;
   if ((epilogue & EPI_DGELU) && !aux_in) return HMMC_ERR_ARG;
@@ -166,6 +165,10 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.resid = resid; p.aux_out = aux_out; p.aux_in = aux_in;
   p.M = M; p.N = N; p.K = K; p.sam = sam; p.sak = sak; p.sbk = sbk; p.sbn = sbn; p.ldc = ldc; p.alpha = alpha;
   p.flags = epilogue;
+  // 16-byte accesses only where the leading dimension and base keep every row aligned
+  p.avec = !(a_ld & 3) && !((uintptr_t)A & 15);
+  p.bvec = !(b_ld & 3) && !((uintptr_t)B & 15);
+  p.cvec = !(ldc & 3) && !((uintptr_t)C & 15) && (!aux_out || !((uintptr_t)aux_out & 15));
   long blocks = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
   hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
   return hmmc_launch_status();

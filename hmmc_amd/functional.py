@@ -1,0 +1,285 @@
+"""torch.autograd.Function shims over the HIP kernels, one per fused stage of the hot path, so
+DDP and the optimizer see ordinary parameter gradients.  Activations are kept token-major
+([tokens, D], a sequence's tokens contiguous); the reference's LND layout is a pure permutation.
+
+Stage -> reference lines:
+  VitEmbedFn        modules/module_clip.py:307-313   conv1 patchify, class token, pos-emb, ln_pre
+  TextEmbedFn       modules/module_cross.py:288-291  token embedding + positional embedding
+  ClipTransformerFn modules/module_clip.py:231-268   N x ResidualAttentionBlock (fp16 tower)
+  LnProjFn          modules/module_cross.py:228-237,296-305   ln_post/ln_final + projection (+ row pick)
+  TemporalFn        modules/module_cross.py:193-212  frame pos-emb, 4 fp32 blocks, residual, normalise, mean
+  FinetuneHeadFn    modules/modeling.py:665-672,702-709       hierarchical InfoNCE
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+PER_LAYER = 12   # parameters of one ResidualAttentionBlock, in the order of block_params()
+
+
+def block_params(block):
+    """Flat parameter list of a ResidualAttentionBlock (names as in the reference state_dict)."""
+    return [block.ln_1.weight, block.ln_1.bias, block.attn.in_proj_weight, block.attn.in_proj_bias,
+            block.attn.out_proj.weight, block.attn.out_proj.bias, block.ln_2.weight, block.ln_2.bias,
+            block.mlp.c_fc.weight, block.mlp.c_fc.bias, block.mlp.c_proj.weight, block.mlp.c_proj.bias]
+
+
+def _wgrad16(dy, x):
+    """dW[N',K'] = dy[T,N']^T x[T,K'] (fp16, split-K over tokens)."""
+    T, Np = dy.shape
+    return ops.gemm_f16(dy, x, Np, x.shape[1], T, a_kmajor=False, b_kmajor=False)
+
+
+def _dgrad16(dy, w, aux_in=None, epilogue=0):
+    """dx[T,K'] = dy[T,N'] w[N',K']."""
+    T, Np = dy.shape
+    return ops.gemm_f16(dy, w, T, w.shape[1], Np, a_kmajor=True, b_kmajor=False, aux_in=aux_in, epilogue=epilogue)
+
+
+class VitEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, video4d, conv_w, cls, pos, ln_w, ln_b):
+        n = video4d.shape[0]
+        D, _, p, _ = conv_w.shape
+        L = pos.shape[0]
+        patches = ops.patchify(video4d, p)                                   # [n*L, 3pp] fp16, class rows zero
+        x0 = ops.gemm_f16(patches, conv_w.view(D, -1), n * L, D, 3 * p * p)
+        ops.vit_embed_(x0, cls, pos, L)
+        x, mean, rstd = ops.layernorm_fwd(x0, ln_w, ln_b, 1e-5)
+        ctx.save_for_backward(patches, x0, mean, rstd, ln_w, conv_w)
+        ctx.dims = (n, L, D, p)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        patches, x0, mean, rstd, ln_w, conv_w = ctx.saved_tensors
+        n, L, D, p = ctx.dims
+        dx0, dlw, dlb = ops.layernorm_bwd(dx.contiguous(), x0, ln_w, mean, rstd)
+        dconv = _wgrad16(dx0, patches).view(conv_w.shape)
+        dpos = ops.colsum(dx0.view(n, L * D), out_dtype=torch.float32, round_f16=True).view(L, D)
+        return None, dconv, dpos[0].clone(), dpos, dlw, dlb
+
+
+class TextEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, table, pos):
+        ctx.save_for_backward(ids)
+        ctx.dims = (table.shape[0], pos.shape[0])
+        return ops.text_embed(ids.contiguous(), table, pos)
+
+    @staticmethod
+    def backward(ctx, dx):
+        (ids,) = ctx.saved_tensors
+        vocab, ctx_len = ctx.dims
+        b, L = ids.shape
+        dx = dx.contiguous()
+        D = dx.shape[-1]
+        dtable = ops.text_embed_bwd(ids, dx, vocab)
+        dpos = torch.zeros((ctx_len, D), dtype=torch.float32, device=dx.device)
+        dpos[:L] = ops.colsum(dx.view(b, L * D), out_dtype=torch.float32, round_f16=True).view(L, D)
+        return None, dtable, dpos
+
+
+class ClipTransformerFn(torch.autograd.Function):
+    """All layers of a CLIP tower in one autograd node (fp16 activations, fp32 LayerNorm statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, nseq, L, heads, causal, *params):
+        nl = len(params) // PER_LAYER
+        T, D = x.shape
+        saved = []
+        keep = any(ctx.needs_input_grad)       # momentum (key) encoders and eval run under no_grad
+        for i in range(nl):
+            (l1w, l1b, inw, inb, ow, ob, l2w, l2b, fcw, fcb, pw, pb) = params[i * PER_LAYER:(i + 1) * PER_LAYER]
+            ln1, m1, r1 = ops.layernorm_fwd(x, l1w, l1b, 1e-5)
+            qkv = ops.gemm_f16(ln1, inw, T, 3 * D, D, bias=inb)
+            att, lse = ops.attention_f16_fwd(qkv, nseq, L, heads, causal)
+            x1 = ops.gemm_f16(att, ow, T, D, D, bias=ob, resid=x)
+            ln2, m2, r2 = ops.layernorm_fwd(x1, l2w, l2b, 1e-5)
+            g, h = ops.gemm_f16(ln2, fcw, T, 4 * D, D, bias=fcb, epilogue=ops.EPI_QGELU, want_aux=True)
+            x2 = ops.gemm_f16(g, pw, T, D, 4 * D, bias=pb, resid=x1)
+            if keep:
+                saved.append([x, m1, r1, ln1, qkv, att, lse, x1, m2, r2, ln2, h, g])
+            x = x2
+        ctx.saved = saved
+        ctx.params = params
+        ctx.cfg = (nseq, L, heads, causal)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        nseq, L, heads, causal = ctx.cfg
+        params = ctx.params
+        nl = len(params) // PER_LAYER
+        grads = [None] * len(params)
+        dx = dx.contiguous()
+        for i in reversed(range(nl)):
+            (l1w, l1b, inw, inb, ow, ob, l2w, l2b, fcw, fcb, pw, pb) = params[i * PER_LAYER:(i + 1) * PER_LAYER]
+            x, m1, r1, ln1, qkv, att, lse, x1, m2, r2, ln2, h, g = ctx.saved[i]
+            ctx.saved[i] = None
+            d_pw = _wgrad16(dx, g)
+            d_pb = ops.colsum(dx)
+            dh = _dgrad16(dx, pw, aux_in=h, epilogue=ops.EPI_DGELU)
+            del g
+            d_fcw = _wgrad16(dh, ln2)
+            d_fcb = ops.colsum(dh)
+            dln2 = _dgrad16(dh, fcw)
+            del dh, h, ln2
+            dx1, d_l2w, d_l2b = ops.layernorm_bwd(dln2, x1, l2w, m2, r2, dres=dx)
+            d_ow = _wgrad16(dx1, att)
+            d_ob = ops.colsum(dx1)
+            datt = _dgrad16(dx1, ow)
+            dqkv = ops.attention_f16_bwd(qkv, att, lse, datt, nseq, L, heads, causal)
+            del att, qkv, datt
+            d_inw = _wgrad16(dqkv, ln1)
+            d_inb = ops.colsum(dqkv)
+            dln1 = _dgrad16(dqkv, inw)
+            dx, d_l1w, d_l1b = ops.layernorm_bwd(dln1, x, l1w, m1, r1, dres=dx1)
+            grads[i * PER_LAYER:(i + 1) * PER_LAYER] = [d_l1w, d_l1b, d_inw, d_inb, d_ow, d_ob, d_l2w, d_l2b, d_fcw,
+                                                        d_fcb, d_pw, d_pb]
+        ctx.saved = None
+        return (dx, None, None, None, None, *grads)
+
+
+class LnProjFn(torch.autograd.Function):
+    """feat = float( LN(x[rows]) @ proj ); rows = row_index (CLS / EOT rows) or all rows."""
+
+    @staticmethod
+    def forward(ctx, x, row_index, ln_w, ln_b, proj):
+        D, E = proj.shape
+        y, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, 1e-5, row_index=row_index)
+        R = y.shape[0]
+        f16 = ops.gemm_f16(y, proj, R, E, D, a_kmajor=True, b_kmajor=False)
+        ctx.save_for_backward(x, row_index, ln_w, proj, y, mean, rstd)
+        return f16.float()
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, row_index, ln_w, proj, y, mean, rstd = ctx.saved_tensors
+        D, E = proj.shape
+        R = y.shape[0]
+        d16 = dout.contiguous().half()
+        dy = ops.gemm_f16(d16, proj, R, D, E, a_kmajor=True, b_kmajor=True)          # dy = d16 @ proj^T
+        dproj = ops.gemm_f16(y, d16, D, E, R, a_kmajor=False, b_kmajor=False)        # y^T d16
+        if row_index is not None:
+            dx = torch.zeros_like(x)
+            dx, dlw, dlb = ops.layernorm_bwd(dy, x, ln_w, mean, rstd, row_index=row_index, dx=dx)
+        else:
+            dx, dlw, dlb = ops.layernorm_bwd(dy, x, ln_w, mean, rstd)
+        return dx, None, dlw, dlb, dproj
+
+
+def _f32_block_fwd(x, rows, seqs, L, H, causal, eps, p):
+    (l1w, l1b, inw, inb, ow, ob, l2w, l2b, fcw, fcb, pw, pb) = p
+    ln1, m1, r1 = ops.layernorm_fwd(x, l1w, l1b, eps)
+    qkv = ops.linear_f32(ln1, inw, bias=inb)
+    att, probs = ops.attention_f32_fwd(qkv, seqs, L, H, causal)
+    x1 = ops.linear_f32(att, ow, bias=ob, resid=x)
+    ln2, m2, r2 = ops.layernorm_fwd(x1, l2w, l2b, eps)
+    g, h = ops.linear_f32(ln2, fcw, bias=fcb, epilogue=ops.EPI_QGELU, want_aux=True)
+    x2 = ops.linear_f32(g, pw, bias=pb, resid=x1)
+    return x2, [x, m1, r1, ln1, qkv, att, probs, x1, m2, r2, ln2, h, g]
+
+
+def _f32_block_bwd(dx, saved, seqs, L, H, p):
+    (l1w, l1b, inw, inb, ow, ob, l2w, l2b, fcw, fcb, pw, pb) = p
+    x, m1, r1, ln1, qkv, att, probs, x1, m2, r2, ln2, h, g = saved
+    d_pw = ops.wgrad_f32(dx, g)
+    d_pb = ops.colsum(dx)
+    dh = ops.dgrad_f32(dx, pw, aux_in=h, epilogue=ops.EPI_DGELU)
+    d_fcw = ops.wgrad_f32(dh, ln2)
+    d_fcb = ops.colsum(dh)
+    dln2 = ops.dgrad_f32(dh, fcw)
+    dx1, d_l2w, d_l2b = ops.layernorm_bwd(dln2, x1, l2w, m2, r2, dres=dx)
+    d_ow = ops.wgrad_f32(dx1, att)
+    d_ob = ops.colsum(dx1)
+    datt = ops.dgrad_f32(dx1, ow)
+    dqkv = ops.attention_f32_bwd(qkv, probs, datt, seqs, L, H)
+    d_inw = ops.wgrad_f32(dqkv, ln1)
+    d_inb = ops.colsum(dqkv)
+    dln1 = ops.dgrad_f32(dqkv, inw)
+    dx0, d_l1w, d_l1b = ops.layernorm_bwd(dln1, x, l1w, m1, r1, dres=dx1)
+    return dx0, [d_l1w, d_l1b, d_inw, d_inb, d_ow, d_ob, d_l2w, d_l2b, d_fcw, d_fcb, d_pw, d_pb]
+
+
+class TemporalFn(torch.autograd.Function):
+    """video_emb = mean_f normalise( TemporalTransformer(u + pos) + u ); fp32 throughout, TF-style LN eps 1e-12."""
+
+    @staticmethod
+    def forward(ctx, u, heads, pos_table, *params):
+        b, F, E = u.shape
+        u2 = u.contiguous().view(b * F, E)
+        nl = len(params) // PER_LAYER
+        saved = []
+        if nl:
+            x = ops.add_rowbias(u2, pos_table, F)
+            for i in range(nl):
+                x, s = _f32_block_fwd(x, b * F, b, F, heads, False, 1e-12, params[i * PER_LAYER:(i + 1) * PER_LAYER])
+                saved.append(s)
+            out, norms = ops.temporal_pool_fwd(x, u2, b, F, E)
+        else:
+            x = u2
+            out, norms = ops.temporal_pool_fwd(x, None, b, F, E)
+        ctx.saved = saved
+        ctx.params = params
+        ctx.fin = (x, u2, norms, pos_table)
+        ctx.cfg = (b, F, E, heads)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, F, E, heads = ctx.cfg
+        x, u2, norms, pos_table = ctx.fin
+        params = ctx.params
+        nl = len(params) // PER_LAYER
+        grads = [None] * len(params)
+        dvf = ops.temporal_pool_bwd(x, u2 if nl else None, norms, dout.contiguous(), b, F, E)
+        if not nl:
+            return dvf.view(b, F, E), None, None
+        dx = dvf
+        for i in reversed(range(nl)):
+            dx, g = _f32_block_bwd(dx, ctx.saved[i], b, F, heads, params[i * PER_LAYER:(i + 1) * PER_LAYER])
+            ctx.saved[i] = None
+            grads[i * PER_LAYER:(i + 1) * PER_LAYER] = g
+        dpos = torch.zeros_like(pos_table)
+        dpos[:F] = ops.colsum(dx.view(b, F * E)).view(F, E)
+        du = dx + dvf                                   # through (u + pos) and through the residual
+        ctx.saved = None
+        return (du.view(b, F, E), None, dpos, *grads)
+
+
+class FinetuneHeadFn(torch.autograd.Function):
+    """loss = w_vtm (CE(S) + CE(S^T)) + w_ftm/F sum_f (CE(S_f) + CE(S_f^T)),  S = 100 n(q) n(.)^T."""
+
+    @staticmethod
+    def forward(ctx, q, v, u, w_vtm, w_ftm, scale):
+        B, E = q.shape
+        F = u.shape[1] if u is not None else 0
+        keys = torch.empty((B * (1 + F), E), dtype=torch.float32, device=q.device)
+        qn, qnorm = ops.l2norm_fwd(q.contiguous())
+        _, vnorm = ops.l2norm_fwd(v.contiguous(), out=keys[:B])
+        unorm = None
+        if F:
+            _, unorm = ops.l2norm_fwd(u.contiguous().view(B * F, E), out=keys[B:])
+        C = B * (1 + F)
+        S = ops.gemm_f32(qn, keys, B, C, E, (E, 1), (1, E), alpha=scale)
+        wf = w_ftm / F if F else 0.0
+        loss, lse_row, lse_col = ops.infonce_fwd(S, B, F, w_vtm, wf)
+        ctx.save_for_backward(qn, qnorm, keys, vnorm, unorm, S, lse_row, lse_col)
+        ctx.cfg = (B, F, E, w_vtm, wf, scale)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        qn, qnorm, keys, vnorm, unorm, S, lse_row, lse_col = ctx.saved_tensors
+        B, F, E, w_vtm, wf, scale = ctx.cfg
+        C = B * (1 + F)
+        dS = ops.infonce_bwd(S, lse_row, lse_col, gout, B, F, w_vtm, wf)
+        dqn = ops.gemm_f32(dS, keys, B, E, C, (C, 1), (E, 1), alpha=scale)          # dS @ keys
+        dkeys = ops.gemm_f32(dS, qn, C, E, B, (1, C), (E, 1), alpha=scale)          # dS^T @ qn
+        dq = ops.l2norm_bwd(dqn, qn, qnorm)
+        dv = ops.l2norm_bwd(dkeys[:B], keys[:B], vnorm)
+        du = ops.l2norm_bwd(dkeys[B:], keys[B:], unorm).view(B, F, E) if F else None
+        return dq, dv, du, None, None, None

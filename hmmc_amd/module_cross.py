@@ -1,0 +1,209 @@
+"""Encoders with the reference's names and forward signatures (reference: modules/module_cross.py:47-108
+CrossConfig, :110-149 temporal blocks, :152-237 VisualEncoder, :240-305 TextEncoder, :308-357 MLM head)."""
+from __future__ import annotations
+
+import copy
+import json
+import logging
+import math
+import os
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import functional as Fn
+from . import ops
+from .module_clip import CLIP, build_model
+from .until_module import LayerNorm
+
+logger = logging.getLogger(__name__)
+
+CONFIG_NAME = "cross_config.json"
+
+
+class CrossConfig(object):
+    """Holds cross-base/cross_config.json (reference modules/module_cross.py:47-108, until_config.py:41-99)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    @classmethod
+    def from_json_file(cls, path):
+        with open(path, "r", encoding="utf-8") as fh:
+            return cls(**json.load(fh))
+
+    @classmethod
+    def get_config(cls, pretrained_model_name, cache_dir=None, type_vocab_size=2, state_dict=None, task_config=None):
+        here = os.path.dirname(os.path.abspath(__file__))
+        cand = os.path.join(here, pretrained_model_name)
+        path = cand if os.path.exists(cand) else pretrained_model_name
+        cfg_file = os.path.join(path, CONFIG_NAME) if os.path.isdir(path) else path
+        if not os.path.exists(cfg_file):
+            if task_config is None or getattr(task_config, "local_rank", 0) == 0:
+                logger.error("Model name '%s' was not found (looked for %s)", pretrained_model_name, cfg_file)
+            return None
+        config = cls.from_json_file(cfg_file)
+        config.type_vocab_size = type_vocab_size
+        return config, state_dict
+
+    def to_dict(self):
+        return copy.deepcopy(self.__dict__)
+
+    def __repr__(self):
+        return json.dumps(self.to_dict(), indent=2, sort_keys=True)
+
+
+class QuickGELU(nn.Module):
+    def forward(self, x):
+        raise RuntimeError("QuickGELU is fused into hmmc_gemm_f32's epilogue; call the enclosing Transformer")
+
+
+class ResidualAttentionBlock(nn.Module):
+    """fp32 temporal block container, TF-style LN eps 1e-12 (reference modules/module_cross.py:114-139)."""
+
+    def __init__(self, d_model, n_head):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(d_model, n_head)
+        self.ln_1 = LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(d_model, d_model * 4)), ("gelu", QuickGELU()),
+                                              ("c_proj", nn.Linear(d_model * 4, d_model))]))
+        self.ln_2 = LayerNorm(d_model)
+        self.n_head = n_head
+
+
+class Transformer(nn.Module):
+    """Temporal transformer container (reference modules/module_cross.py:141-149); executed inside
+    functional.TemporalFn together with the position add, the residual and the pooling."""
+
+    def __init__(self, width, layers, heads):
+        super().__init__()
+        self.width, self.layers, self.heads = width, layers, heads
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+    def flat_params(self):
+        out = []
+        for blk in self.resblocks:
+            out += Fn.block_params(blk)
+        return out
+
+
+def _clip_for(task_config, cross_config):
+    name = getattr(task_config, "pretrained_clip_name", None) or cross_config.pretrained_clip_name
+    sd = getattr(cross_config, "_clip_state_dict", None)
+    if sd is None:
+        sd = CLIP.get_config(pretrained_clip_name=name)
+    return sd, build_model(sd, local_rank=getattr(task_config, "local_rank", 0))
+
+
+class VisualEncoder(nn.Module):
+    """video [b,F,3,H,W] -> (video_emb [b,512], frame_output [b,F,512]) fp32
+    (reference modules/module_cross.py:152-237)."""
+
+    def __init__(self, task_config, cross_config):
+        super().__init__()
+        _, clip = _clip_for(task_config, cross_config)
+        self.use_temp = task_config.use_temp
+        self.is_vit = True
+        self.visual = copy.deepcopy(clip.visual)
+        if self.use_temp:
+            self.temporal_transformer = Transformer(width=cross_config.temporal_hidden_size,
+                                                    layers=cross_config.temporal_hidden_layers,
+                                                    heads=cross_config.temporal_attention_heads)
+            self.frame_position_embeddings = nn.Embedding(cross_config.max_position_embeddings,
+                                                          cross_config.temporal_hidden_size)
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    def forward(self, video, video_frames=None):
+        bs, frames, channel, h, w = video.shape
+        video = video.reshape(bs * frames, channel, h, w)
+        frame_output = self.encode_image(video, video_frame=frames).view(bs, frames, -1)
+        if self.use_temp:
+            if frames > self.frame_position_embeddings.weight.shape[0]:
+                raise ValueError("more frames than max_position_embeddings")
+            visual_output = Fn.TemporalFn.apply(frame_output, self.temporal_transformer.heads,
+                                                self.frame_position_embeddings.weight,
+                                                *self.temporal_transformer.flat_params())
+        else:
+            visual_output = Fn.TemporalFn.apply(frame_output, 0, None)
+        return visual_output, frame_output
+
+    def encode_image(self, image, return_hidden=False, video_frame=-1):
+        """ln_post(hidden) @ proj, CLS row, .float() (reference modules/module_cross.py:222-237).  Only the CLS
+        rows are normalised and projected unless return_hidden asks for all tokens."""
+        n = image.shape[0]
+        L = self.visual.tokens
+        tokens = self.visual.hidden_tokens(image)
+        v = self.visual
+        if return_hidden:
+            hidden = Fn.LnProjFn.apply(tokens, None, v.ln_post.weight, v.ln_post.bias, v.proj).view(n, L, -1)
+            return hidden[:, 0, :], hidden
+        idx = torch.arange(n, device=tokens.device, dtype=torch.int32) * L
+        return Fn.LnProjFn.apply(tokens, idx, v.ln_post.weight, v.ln_post.bias, v.proj)
+
+
+class TextEncoder(nn.Module):
+    """CLIP text transformer (english branch; reference modules/module_cross.py:240-305)."""
+
+    def __init__(self, task_config, cross_config):
+        super().__init__()
+        self.language = task_config.language
+        if self.language != "english":
+            raise NotImplementedError("only the CLIP (english) text transformer is on the HMMC hot path")
+        clip_state_dict, clip = _clip_for(task_config, cross_config)
+        self.logit_scale = copy.deepcopy(clip_state_dict["logit_scale"]).float()    # plain tensor attribute, ln(100)
+        self.token_embedding = copy.deepcopy(clip.token_embedding)
+        self.positional_embedding = copy.deepcopy(clip.positional_embedding)
+        self.transformer = copy.deepcopy(clip.transformer)
+        self.ln_final = copy.deepcopy(clip.ln_final)
+        self.text_projection = copy.deepcopy(clip.text_projection)
+        self.dtype = clip.visual.conv1.weight.dtype
+
+    def forward(self, input_ids, attention_mask=None, return_hidden=False):
+        bs_pair = input_ids.size(0)
+        text_output, hidden = self.encode_text(input_ids, return_hidden=True, _want=("hidden" if return_hidden else "feat"))
+        if return_hidden:
+            return hidden.view(bs_pair, -1, hidden.size(-1))
+        return text_output.view(bs_pair, text_output.size(-1))
+
+    def encode_text(self, text, return_hidden=False, _want="both"):
+        b, L = text.shape
+        if L > self.positional_embedding.shape[0]:
+            raise ValueError("sequence longer than the positional embedding table")
+        x = Fn.TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)
+        x = self.transformer(x, b, L)
+        feat = hidden = None
+        if _want in ("both", "hidden"):
+            hidden = Fn.LnProjFn.apply(x, None, self.ln_final.weight, self.ln_final.bias, self.text_projection).view(b, L, -1)
+        if _want in ("both", "feat"):
+            idx = (torch.arange(b, device=text.device) * L + text.argmax(dim=-1)).to(torch.int32)   # EOT = largest id
+            feat = Fn.LnProjFn.apply(x, idx, self.ln_final.weight, self.ln_final.bias, self.text_projection)
+        if return_hidden:
+            return feat, hidden
+        return feat
+
+
+class BertLayerNorm(LayerNorm):
+    pass
+
+
+class BertPredictionHeadTransform(nn.Module):
+    def __init__(self, hidden_size, hidden_act="gelu"):
+        super().__init__()
+        self.dense = nn.Linear(hidden_size, hidden_size)
+        self.hidden_act = hidden_act
+        self.LayerNorm = BertLayerNorm(hidden_size, eps=1e-12)
+
+
+class BertLMPredictionHead(nn.Module):
+    """MLM head container (reference modules/module_cross.py:308-357): dense, erf-GELU, LN(1e-12), decoder to vocab."""
+
+    def __init__(self, hidden_size, vocab_size, hidden_act="gelu"):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(hidden_size, hidden_act)
+        self.decoder = nn.Linear(hidden_size, vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(vocab_size))
+        self.decoder.bias = self.bias

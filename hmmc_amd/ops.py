@@ -15,6 +15,29 @@ EPI_BIAS, EPI_RESID, EPI_QGELU, EPI_DGELU = 1, 2, 4, 8
 
 _ws_cache = {}
 
+# optional live timing of the dominant kernel (bench.py): HIP events on the launch stream around every
+# hmmc_gemm_f16 call, keyed by operand layout
+_gemm_prof = None
+
+
+def gemm_profile_start():
+    global _gemm_prof
+    _gemm_prof = []
+
+
+def gemm_profile_stop():
+    """-> {layout: {"flops", "seconds", "launches"}} (synchronises)."""
+    global _gemm_prof
+    rec, _gemm_prof = _gemm_prof or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for key, flops, e0, e1 in rec:
+        d = out.setdefault(key, {"flops": 0.0, "seconds": 0.0, "launches": 0})
+        d["flops"] += flops
+        d["seconds"] += e0.elapsed_time(e1) * 1e-3
+        d["launches"] += 1
+    return out
+
 
 def workspace(nbytes, device, tag="default"):
     """Grow-only scratch buffer per (device, tag); kernels never allocate."""
@@ -52,12 +75,20 @@ def gemm_f16(a, b, M, N, K, a_kmajor=True, b_kmajor=True, bias=None, resid=None,
         epilogue |= EPI_BIAS
     if resid is not None:
         assert tuple(resid.shape) == (M, N)
+        epilogue |= EPI_RESID
     if aux_in is not None:
         assert tuple(aux_in.shape) == (M, N)
     wsb = 0 if epilogue else query("hmmc_gemm_f16_workspace", M, N, K)
     ws = workspace(wsb, a.device, "gemm") if wsb else None
+    if _gemm_prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("hmmc_gemm_f16", ptr(a), ptr(b), ptr(c), M, N, K, a.shape[1], b.shape[1], N, int(a_kmajor), int(b_kmajor),
          ptr(bias), ptr(resid), ptr(aux_out), ptr(aux_in), epilogue, ptr(ws), wsb)
+    if _gemm_prof is not None:
+        e1.record()
+        key = ("fwd_kk" if b_kmajor else "dgrad_km") if a_kmajor else ("wgrad_mm" if not b_kmajor else "mk")
+        _gemm_prof.append((key, 2.0 * M * N * K, e0, e1))
     return (c, aux_out) if want_aux else c
 
 
@@ -169,3 +200,142 @@ def attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal):
     dqkv = torch.empty_like(qkv)
     call("hmmc_attention_f16_bwd", ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), nseq, L, H, int(causal))
     return dqkv
+
+
+# ----------------------------------------------------------------------------- fp32 side
+
+EPI_RELU = 16
+
+
+def gemm_f32(a, b, M, N, K, sa, sb, alpha=1.0, bias=None, resid=None, aux_in=None, epilogue=0, want_aux=False, out=None):
+    """C[M,N] = epi(alpha * sum_k A[m*sa[0] + k*sa[1]] * B[k*sb[0] + n*sb[1]]); a, b are fp32 buffers (any shape)."""
+    _chk(a, torch.float32, "a")
+    _chk(b, torch.float32, "b")
+    assert (M - 1) * sa[0] + (K - 1) * sa[1] < a.numel(), ("A out of range", M, K, sa, a.shape)
+    assert (K - 1) * sb[0] + (N - 1) * sb[1] < b.numel(), ("B out of range", K, N, sb, b.shape)
+    c = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _chk(c, torch.float32, "out")
+    assert c.numel() == M * N
+    aux_out = torch.empty_like(c) if want_aux else None
+    for t, n in ((bias, "bias"), (resid, "resid"), (aux_in, "aux_in")):
+        if t is not None:
+            _chk(t, torch.float32, n)
+    if bias is not None:
+        assert bias.numel() == N
+        epilogue |= EPI_BIAS
+    if resid is not None:
+        assert resid.numel() == M * N
+        epilogue |= EPI_RESID
+    if aux_in is not None:
+        assert aux_in.numel() == M * N
+    call("hmmc_gemm_f32", ptr(a), ptr(b), ptr(c), M, N, K, sa[0], sa[1], sb[0], sb[1], N, float(alpha), ptr(bias),
+         ptr(resid), ptr(aux_out), ptr(aux_in), epilogue)
+    return (c, aux_out) if want_aux else c
+
+
+def linear_f32(x, w, bias=None, resid=None, epilogue=0, want_aux=False, aux_in=None):
+    """y = x @ w.T (+bias): x [M,K], w [N,K]."""
+    M, K = x.shape
+    N = w.shape[0]
+    return gemm_f32(x, w, M, N, K, (K, 1), (1, K), bias=bias, resid=resid, epilogue=epilogue, want_aux=want_aux,
+                    aux_in=aux_in)
+
+
+def dgrad_f32(dy, w, aux_in=None, epilogue=0):
+    """dx = dy @ w: dy [M,N'], w [N',K'] -> [M,K']."""
+    M, Np = dy.shape
+    Kp = w.shape[1]
+    return gemm_f32(dy, w, M, Kp, Np, (Np, 1), (Kp, 1), aux_in=aux_in, epilogue=epilogue)
+
+
+def wgrad_f32(dy, x):
+    """dW = dy.T @ x: dy [T,N'], x [T,K'] -> [N',K']."""
+    T, Np = dy.shape
+    Kp = x.shape[1]
+    return gemm_f32(dy, x, Np, Kp, T, (1, Np), (Kp, 1))
+
+
+def l2norm_fwd(x, eps=0.0, out=None):
+    _chk(x, torch.float32, "x")
+    rows, D = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    norm = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call("hmmc_l2norm_fwd", ptr(x), ptr(y), ptr(norm), rows, D, float(eps))
+    return y, norm
+
+
+def l2norm_bwd(dy, y, norm):
+    _chk(dy, torch.float32, "dy")
+    rows, D = y.shape
+    dx = torch.empty_like(y)
+    call("hmmc_l2norm_bwd", ptr(dy), ptr(y), ptr(norm), ptr(dx), rows, D)
+    return dx
+
+
+def infonce_fwd(S, B, F, w_video, w_frame):
+    _chk(S, torch.float32, "S")
+    assert tuple(S.shape) == (B, B * (1 + F))
+    lse_row = torch.empty((B, 1 + F), dtype=torch.float32, device=S.device)
+    lse_col = torch.empty(B * (1 + F), dtype=torch.float32, device=S.device)
+    loss = torch.empty((), dtype=torch.float32, device=S.device)
+    call("hmmc_infonce_fwd", ptr(S), ptr(lse_row), ptr(lse_col), ptr(loss), B, F, float(w_video), float(w_frame))
+    return loss, lse_row, lse_col
+
+
+def infonce_bwd(S, lse_row, lse_col, gout, B, F, w_video, w_frame):
+    gout = gout.contiguous().float()
+    dS = torch.empty_like(S)
+    call("hmmc_infonce_bwd", ptr(S), ptr(lse_row), ptr(lse_col), ptr(gout), ptr(dS), B, F, float(w_video), float(w_frame))
+    return dS
+
+
+def topk_mean(S_frame, bq, bv, F, k, base=None, lds=None, ldb=None):
+    """out[i][b] = base[i][b] + mean(topk_f S_frame[i][b*F+f])."""
+    _chk(S_frame, torch.float32, "S_frame")
+    out = torch.empty((bq, bv), dtype=torch.float32, device=S_frame.device)
+    call("hmmc_topk_mean", ptr(S_frame), ptr(base), ptr(out), bq, bv, F, k, lds or bv * F, ldb or bv)
+    return out
+
+
+def temporal_pool_fwd(h, u, b, F, D):
+    out = torch.empty((b, D), dtype=torch.float32, device=h.device)
+    norms = torch.empty((b, F), dtype=torch.float32, device=h.device)
+    call("hmmc_temporal_pool_fwd", ptr(h), ptr(u), ptr(out), ptr(norms), b, F, D)
+    return out, norms
+
+
+def temporal_pool_bwd(h, u, norms, dout, b, F, D):
+    dout = dout.contiguous()
+    dvf = torch.empty((b * F, D), dtype=torch.float32, device=h.device)
+    call("hmmc_temporal_pool_bwd", ptr(h), ptr(u), ptr(norms), ptr(dout), ptr(dvf), b, F, D)
+    return dvf
+
+
+def add_rowbias(x, table, period):
+    rows, D = x.shape
+    out = torch.empty_like(x)
+    call("hmmc_add_rowbias", ptr(x), ptr(table), ptr(out), rows, period, D)
+    return out
+
+
+def attention_f32_fwd(qkv, b, F, H, causal=False):
+    _chk(qkv, torch.float32, "qkv")
+    D = H * 64
+    out = torch.empty((b * F, D), dtype=torch.float32, device=qkv.device)
+    probs = torch.empty((b, H, F, F), dtype=torch.float32, device=qkv.device)
+    call("hmmc_temporal_attention_fwd", ptr(qkv), ptr(out), ptr(probs), b, F, H, int(causal))
+    return out, probs
+
+
+def attention_f32_bwd(qkv, probs, dout, b, F, H):
+    dqkv = torch.empty_like(qkv)
+    call("hmmc_temporal_attention_bwd", ptr(qkv), ptr(probs), ptr(dout), ptr(dqkv), b, F, H)
+    return dqkv
+
+
+def enqueue(keys, queue, col0):
+    _chk(keys, torch.float32, "keys")
+    _chk(queue, torch.float32, "queue")
+    R, E = keys.shape
+    assert queue.shape[0] == E
+    call("hmmc_enqueue", ptr(keys), ptr(queue), R, E, queue.shape[1], int(col0))

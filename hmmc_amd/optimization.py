@@ -1,0 +1,174 @@
+"""BertAdam with the reference's constructor / step() / get_lr() / state layout
+(reference modules/optimization.py:26-168), executed as TWO multi-tensor HIP launches per step
+(per-parameter gradient norms, then the fused clip + moment + weight update) instead of ~10 tiny
+launches for each of the 350-560 parameters.  Arithmetic follows the reference's tensor expressions op by
+op in each parameter's own dtype (fp16 parameters keep fp16 moments), no bias correction, step counter
+starting at 0 so the first update uses lr 0 under warm-up.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from torch.optim import Optimizer
+from torch.optim.optimizer import required
+
+from ._lib import call, load, ptr
+
+
+def warmup_cosine(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return 0.5 * (1.0 + math.cos(math.pi * x))
+
+
+def warmup_constant(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return 1.0
+
+
+def warmup_linear(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return max((x - 1.) / (warmup - 1.), 0)
+
+
+SCHEDULES = {"warmup_cosine": warmup_cosine, "warmup_constant": warmup_constant, "warmup_linear": warmup_linear}
+
+
+class _TensorTable:
+    """Device-side pointer/chunk tables for the multi-tensor kernels (rebuilt when pointers change)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.key = None
+        self.chunk_elems = load().hmmc_mt_chunk_elems()
+
+    def build(self, rows):
+        """rows: list of (ptr0, ptr1, ptr2, ptr3, numel, dtype_flag)."""
+        key = tuple(rows)
+        if key != self.key:
+            arr = np.zeros((len(rows), 8), dtype=np.int64)
+            arr[:, :6] = np.asarray(rows, dtype=np.int64)
+            nch = (arr[:, 4] + self.chunk_elems - 1) // self.chunk_elems
+            tidx = np.repeat(np.arange(len(rows)), nch)
+            cidx = np.concatenate([np.arange(n) for n in nch]) if len(rows) else np.zeros(0, dtype=np.int64)
+            chunks = np.stack([tidx, cidx], axis=1).astype(np.int32)
+            self.tab = torch.from_numpy(arr).to(self.device, non_blocking=True)
+            self.chunk = torch.from_numpy(chunks).to(self.device, non_blocking=True)
+            self.nchunks = int(chunks.shape[0])
+            self.T = len(rows)
+            self.sumsq = torch.zeros(len(rows), dtype=torch.float32, device=self.device)
+            self.key = key
+        return self
+
+
+def _dtype_flag(t):
+    if t.dtype == torch.float16:
+        return 0
+    if t.dtype == torch.float32:
+        return 1
+    raise TypeError(f"unsupported parameter dtype {t.dtype}")
+
+
+_clip_tables = {}
+
+
+def clip_grad_norm_(parameters, max_norm):
+    """torch.nn.utils.clip_grad_norm_(parameters, max_norm) semantics (main_task_retrieval.py:291) in three
+    launches over all gradients.  Returns the total norm (0-dim device tensor, no host sync)."""
+    params = [p for p in parameters if p.grad is not None]
+    if not params:
+        return torch.zeros(())
+    dev = params[0].grad.device
+    tbl = _clip_tables.setdefault(str(dev), _TensorTable(dev))
+    rows = [(0, p.grad.data_ptr(), 0, 0, p.grad.numel(), _dtype_flag(p.grad)) for p in params]
+    for p in params:
+        if not p.grad.is_contiguous():
+            raise ValueError("gradients must be contiguous")
+    tbl.build(rows)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    call("hmmc_mt_clip_grad_norm", ptr(tbl.tab), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T, float(max_norm), ptr(out))
+    return out[1]
+
+
+class BertAdam(Optimizer):
+    """Implements BERT version of Adam algorithm with weight decay fix (same arguments as the reference)."""
+
+    def __init__(self, params, lr=required, warmup=-1, t_total=-1, schedule="warmup_linear", b1=0.9, b2=0.999, e=1e-6,
+                 weight_decay=0.01, max_grad_norm=1.0):
+        if lr is not required and lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if schedule not in SCHEDULES:
+            raise ValueError("Invalid schedule parameter: {}".format(schedule))
+        if not 0.0 <= warmup < 1.0 and not warmup == -1:
+            raise ValueError("Invalid warmup: {} - should be in [0.0, 1.0[ or -1".format(warmup))
+        if not 0.0 <= b1 < 1.0:
+            raise ValueError("Invalid b1 parameter: {} - should be in [0.0, 1.0[".format(b1))
+        if not 0.0 <= b2 < 1.0:
+            raise ValueError("Invalid b2 parameter: {} - should be in [0.0, 1.0[".format(b2))
+        if not e >= 0.0:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(e))
+        defaults = dict(lr=lr, schedule=schedule, warmup=warmup, t_total=t_total, b1=b1, b2=b2, e=e,
+                        weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        super().__init__(params, defaults)
+        self._table = None
+
+    def get_lr(self):
+        lr = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                if len(state) == 0:
+                    return [0]
+                if group["t_total"] != -1:
+                    lr_scheduled = group["lr"] * SCHEDULES[group["schedule"]](state["step"] / group["t_total"], group["warmup"])
+                else:
+                    lr_scheduled = group["lr"]
+                lr.append(lr_scheduled)
+        return lr
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        rows, frows = [], []
+        dev = None
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
+                if not (p.is_contiguous() and p.grad.is_contiguous()) or p.grad.dtype != p.dtype:
+                    raise ValueError("BertAdam (HIP) needs contiguous parameters and same-dtype gradients")
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = 0
+                    state["next_m"] = torch.zeros_like(p.data)
+                    state["next_v"] = torch.zeros_like(p.data)
+                if group["t_total"] != -1:
+                    lr_s = group["lr"] * SCHEDULES[group["schedule"]](state["step"] / group["t_total"], group["warmup"])
+                else:
+                    lr_s = group["lr"]
+                dev = p.device
+                rows.append((p.data_ptr(), p.grad.data_ptr(), state["next_m"].data_ptr(), state["next_v"].data_ptr(),
+                             p.numel(), _dtype_flag(p)))
+                frows.append((lr_s, group["weight_decay"], group["b1"], group["b2"], group["e"], group["max_grad_norm"], 0.0, 0.0))
+                state["step"] += 1
+        if not rows:
+            return loss
+        if dev.type != "cuda":
+            raise RuntimeError("hmmc_amd.BertAdam runs on the GPU only (no CPU fallback)")
+        if self._table is None:
+            self._table = _TensorTable(dev)
+        tbl = self._table.build(rows)
+        ftab = torch.tensor(frows, dtype=torch.float32).to(dev, non_blocking=True)
+        call("hmmc_mt_bertadam", ptr(tbl.tab), ptr(ftab), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T)
+        return loss

@@ -89,6 +89,63 @@ int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, int nseq, int
 int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, int nseq,
                            int L, int H, int causal, hmmc_stream_t stream);
 
+/* fp32 MFMA GEMM (exact f32 FMA chain) with general strides: C[m][n] = epi(alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]);
+ * one stride of each operand must be 1.  Epilogue flags as hmmc_gemm_f16 plus HMMC_EPI_RELU; QuickGELU is evaluated in fp32.
+ * Temporal transformer (modules/module_cross.py:114-149), similarity matrices (modules/modeling.py:207-229,286-313),
+ * projector MLPs (:788-807), MLM head (modules/module_cross.py:308-357). */
+#define HMMC_EPI_RELU 16
+int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn,
+                  int ldc, float alpha, const float* bias, const float* resid, float* aux_out, const float* aux_in,
+                  int epilogue, hmmc_stream_t stream);
+
+/* y = x / max(||x||, eps) per row (eps 0: loose_similarity, modules/modeling.py:210-214; eps 1e-12: F.normalize, :289-292). */
+int hmmc_l2norm_fwd(const float* x, float* y, float* norm, int rows, int D, float eps, hmmc_stream_t stream);
+int hmmc_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx, int rows, int D, hmmc_stream_t stream);
+
+/* Hierarchical InfoNCE of BirdModel.forward (modules/modeling.py:665-672,702-709; CrossEn until_module.py:196-205) on
+ * S_all [B, B*(1+F)] = 100 * Qn [Vn ; Un]^T (column c < B: video c; column B + b*F + f: frame f of video b):
+ * loss = w_video * (CE(S) + CE(S^T)) + w_frame * sum_f (CE(S_f) + CE(S_f^T)), w_frame = weight_FTM / F.
+ * lse_row [B][1+F] and lse_col [B*(1+F)] are saved for the backward; grad_out is a device scalar. */
+int hmmc_infonce_fwd(const float* S, float* lse_row, float* lse_col, float* loss, int B, int F, float w_video, float w_frame,
+                     hmmc_stream_t stream);
+int hmmc_infonce_bwd(const float* S, const float* lse_row, const float* lse_col, const float* grad_out, float* dS, int B,
+                     int F, float w_video, float w_frame, hmmc_stream_t stream);
+
+/* Eval scorer (main_task_retrieval.py:332-336,512-513): out[i][b] = base[i][b] + mean(top-k over f of S_frame[i][b*F + f]). */
+int hmmc_topk_mean(const float* S_frame, const float* base, float* out, int bq, int bv, int F, int k, long lds, long ldb,
+                   hmmc_stream_t stream);
+
+/* video_emb[b] = mean_f (h + u)/||h + u||  (modules/module_cross.py:207-212); u may be NULL (use_temp False). */
+int hmmc_temporal_pool_fwd(const float* h, const float* u, float* out, float* norms, int b, int F, int D,
+                           hmmc_stream_t stream);
+int hmmc_temporal_pool_bwd(const float* h, const float* u, const float* norms, const float* dout, float* dvf, int b, int F,
+                           int D, hmmc_stream_t stream);
+/* out[r] = x[r] + table[r % period]  (frame_position_embeddings, modules/module_cross.py:195-199). */
+int hmmc_add_rowbias(const float* x, const float* table, float* out, long rows, int period, int D, hmmc_stream_t stream);
+/* fp32 attention of the temporal blocks, sequence length F <= 64, head dim 64 (modules/module_cross.py:127-131). */
+int hmmc_temporal_attention_fwd(const float* qkv, float* out, float* probs, int b, int F, int H, int causal,
+                                hmmc_stream_t stream);
+int hmmc_temporal_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int b, int F, int H,
+                                hmmc_stream_t stream);
+
+/* Multi-tensor kernels.  tab: int64 [T][8] = {p, g, m, v device pointers, numel, dtype (0 fp16, 1 fp32), 0, 0};
+ * ftab: float [T][8] = {scheduled lr, weight_decay, b1, b2, eps, max_grad_norm, 0, 0};
+ * chunk: int32 [nchunks][2] = {tensor index, chunk index}, hmmc_mt_chunk_elems() elements per chunk;
+ * sumsq: float [T] scratch. */
+int hmmc_mt_chunk_elems(void);
+int hmmc_mt_sumsq(const long* tab, const int* chunk, int nchunks, float* sumsq, int T, hmmc_stream_t stream);
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) (main_task_retrieval.py:291): out[0] = coefficient, out[1] = total norm. */
+int hmmc_mt_clip_grad_norm(const long* tab, const int* chunk, int nchunks, float* sumsq, int T, float max_norm, float* out,
+                           hmmc_stream_t stream);
+/* BertAdam.step (modules/optimization.py:103-168) for every tensor, including its per-parameter clip. */
+int hmmc_mt_bertadam(const long* tab, const float* ftab, const int* chunk, int nchunks, float* sumsq, int T,
+                     hmmc_stream_t stream);
+/* _momentum_update (modules/modeling.py:238-242); tab rows = {p_k, p, 0, 0, numel, dtype}. */
+int hmmc_mt_ema(const long* tab, const int* chunk, int nchunks, float momentum, float one_minus_momentum,
+                hmmc_stream_t stream);
+/* _dequeue_and_enqueue (modules/modeling.py:262-278): queue[:, col0:col0+R] = normalize(keys).T; queue is [E][W]. */
+int hmmc_enqueue(const float* keys, float* queue, int R, int E, long W, long col0, hmmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

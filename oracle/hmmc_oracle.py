@@ -380,9 +380,11 @@ def bert_adam_step(p, g, m, v, step, lr, t_total, warmup, wd, b1=0.9, b2=0.98, e
     """BertAdam.step for one tensor, modules/optimization.py:103-168, evaluated op by op in the
     tensor's own dtype exactly as the reference's tensor expressions do.  Returns new (p, m, v, g)."""
     if max_grad_norm > 0:
-        norm = torch.linalg.vector_norm(g.float(), 2.0)      # clip_grad_norm_ on this tensor alone (:135-136)
+        # clip_grad_norm_ on this tensor alone (:135-136).  torch evaluates the norm and the clip
+        # coefficient in the gradient's own dtype: for fp16 both are rounded to fp16.
+        norm = torch.linalg.vector_norm(g, 2.0)
         coef = torch.clamp(max_grad_norm / (norm + 1e-6), max=1.0)
-        g = g * coef.to(g.dtype) if g.dtype == torch.float32 else (g.float() * coef).to(g.dtype)
+        g = g * coef
     m = m.mul(b1).add(g, alpha=1 - b1)
     v = v.mul(b2).addcmul(g, g, value=1 - b2)
     update = m / (v.sqrt() + e)

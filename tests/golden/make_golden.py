@@ -230,8 +230,8 @@ def fx_bertadam(mclip, mmodel, mopt, mmetrics):
         out[f"lr{step}"] = np.array(opt.get_lr())
         for (name, *_), p in zip(specs, params):
             st = opt.state[p]
-            out[f"{name}.p{step}"], out[f"{name}.m{step}"], out[f"{name}.v{step}"] = p.data, st["next_m"], st["next_v"]
-            out[f"{name}.g{step}"] = p.grad
+            out[f"{name}.p{step}"], out[f"{name}.m{step}"], out[f"{name}.v{step}"] = p.data.clone(), st["next_m"].clone(), st["next_v"].clone()
+            out[f"{name}.g{step}"] = p.grad.clone()
     save("bertadam", **out)
 
 
@@ -278,9 +278,9 @@ def fx_train_ft(mclip, mmodel, mopt, mmetrics):
             tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
             opt.step()
             opt.zero_grad()
-            out[f"loss{step}"], out[f"gnorm{step}"] = loss, tn
+            out[f"loss{step}"], out[f"gnorm{step}"] = loss.detach().clone(), tn.detach().clone()
             for k in SAMPLED:
-                out[f"p{step}:{k}"] = P[k].data.reshape(-1)[:16]
+                out[f"p{step}:{k}"] = P[k].data.reshape(-1)[:16].clone()
         save(f"train_ft_{mode}", **out)
 
 
@@ -342,7 +342,7 @@ def fx_moco(mclip, mmodel, mopt, mmetrics):
             tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
             opt.step()
             opt.zero_grad()
-            out[f"loss{step}"], out[f"gnorm{step}"] = loss, tn
+            out[f"loss{step}"], out[f"gnorm{step}"] = loss.detach().clone(), tn.detach().clone()
             out[f"fam{step}"], out[f"ftm{step}"], out[f"mlm{step}"] = parts["frame_self_loss"], parts["frame_cross_loss"], \
                 parts["calculate_mlm_loss"]
             out[f"ptr{step}"] = model.queue_ptr.clone()
@@ -352,11 +352,11 @@ def fx_moco(mclip, mmodel, mopt, mmetrics):
                       "v_projector_k.linear_out.weight", "text_encoder_k.ln_final.weight",
                       "v_projector.linear_hidden.2.running_mean", "v_projector.linear_hidden.2.running_var",
                       "v_projector_k.linear_hidden.2.running_mean", "v_predictor.linear_hidden.2.running_var"):
-                out[f"s{step}:{k}"] = S[k].reshape(-1)[:16]
+                out[f"s{step}:{k}"] = S[k].reshape(-1)[:16].clone()
             if step in (0, 3, 4):
                 for qn in ("queue_v_cross_ng", "queue_title_cross_ng", "queue_tag_cross_ng", "queue_frame_proj_ng",
                            "queue_frame_cross_ng"):
-                    out[f"q{step}:{qn}"] = S[qn][:32]   # first 32 of 512 feature rows, all columns
+                    out[f"q{step}:{qn}"] = S[qn][:32].clone()   # first 32 of 512 feature rows, all columns
         save(f"moco_{mode}", **out)
 
 

@@ -19,7 +19,7 @@ def declared():
     for m in re.finditer(r"\b(int|size_t)\s+(hmmc_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.groups()
         codes = ""
-        for a in [x.strip() for x in args.split(",") if x.strip()]:
+        for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
             if "*" in a or "hmmc_stream_t" in a:
                 codes += "p"
             else:
