@@ -59,8 +59,8 @@ def cpu_baseline(frames, length, seconds=20.0):
     """The oracle's fp32 restatement of the same step, timed on this host's cores (rank 0, N=1 only)."""
     from hmmc_amd import synth
     from oracle import hmmc_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))     # the cores this process may actually use
+    torch.set_num_threads(cores)
     B = 4
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in synth.finetune_state(synth.VIT_B32).items()}
     params = [v for v in sd.values() if v.requires_grad]
@@ -80,12 +80,15 @@ def cpu_baseline(frames, length, seconds=20.0):
                     np_, m, v, _ = O.bert_adam_step(p.data, p.grad, m, v, i, 1e-4, 1000, 0.1, 0.2)
                     p.data.copy_(np_)
                     state[k] = (m, v)
+    print(f"[bench] cpu_baseline: oracle step on {cores} host threads ...", file=sys.stderr, flush=True)
     step(0)                      # warm-up
+    print("[bench] cpu_baseline: warm-up step done", file=sys.stderr, flush=True)
     t0 = time.time()
     n = 0
     while n < 2 or (time.time() - t0 < seconds and n < 8):
         step(n + 1)
         n += 1
+        print(f"[bench] cpu_baseline: step {n} at {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
     dt = (time.time() - t0) / n
     return {"value": round(B / dt, 4), "unit": "video-text pairs/s", "cores": cores, "kind": "port",
             "sample": f"oracle fp32 restatement, B={B} F={frames} L={length} ViT-B/32, {n} steps of {dt:.2f} s "
@@ -165,7 +168,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         ms = dt / args.steps * 1e3

@@ -11,9 +11,11 @@
 // dgrad   dx = dy W        : A k-major (dy), B m-major (W[N',K'] indexed [k=n'][r=k'])
 // wgrad   dW = dy^T x      : A m-major (dy), B m-major (x), split-K over tokens
 //
-// Structure: 128x128x64 block tile, 4 waves (2x2, 64x64 each), 16x16x32 f16 MFMA with the
-// operands swapped (MFMA-A = weight rows, MFMA-B = activation rows) so each lane owns 4
-// consecutive n of one output row (8-byte stores).  Tiles are staged by LDS-DMA
+// Structure: two tile configurations of one template — 256x256x64 (8 waves as 2x4, 128x64 per wave,
+// one workgroup per CU, 128 KiB of LDS) for the large tower GEMMs, where it halves the L2->LDS
+// bytes per flop, and 128x128x64 (4 waves as 2x2, 64x64 each, two workgroups per CU) for small or
+// ragged problems.  16x16x32 f16 MFMA with the operands swapped (MFMA-A = weight rows, MFMA-B =
+// activation rows) so each lane owns 4 consecutive n of one output row (8-byte stores).  Tiles are staged by LDS-DMA
 // (buffer_load ... lds, 16 B/lane) through a bounds-checked buffer descriptor: rows past the
 // end of a matrix read as zero, so ragged M/N/K need no branches and cannot fault.
 // LDS images are lane-linear; bank conflicts are removed by XOR-swizzling the per-lane SOURCE
@@ -24,10 +26,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BKT = 64;
-constexpr int TILE_BYTES = BM * BKT * 2;          // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // double buffered: 64 KiB
+constexpr int BKT = 64;
 
 enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8 };
 
@@ -44,29 +43,33 @@ struct GemmArgs {
 // k-major tile image: [128 rows][8 chunks of 16 B]; phys chunk = logical ^ ((row >> 1) & 7)
 // m-major tile image: [64 k-rows][16 chunks of 16 B]; phys chunk = logical ^ f(krow),
 //                     f(krow) = ((krow & 3) << 2) | ((krow >> 2) & 3)
-template <bool KMAJ>
+// R = tile rows (128 or 256), NTH = threads per workgroup; R*8 chunks of 16 B, one per thread per pass.
+template <bool KMAJ, int R, int NTH>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int wid, int tid,
                                            int r0, int k0, int ld) {
+  constexpr int PASSES = R * 8 / NTH;
+  constexpr int CPR = R / 8;                    // chunks per k-row of an m-major image
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < PASSES; ++ps) {
     unsigned goff;
     if (KMAJ) {
-      int row = ps * 32 + (tid >> 3);
+      int row = ps * (NTH / 8) + (tid >> 3);
       int logical = (tid & 7) ^ ((row >> 1) & 7);
       goff = ((unsigned)(r0 + row) * (unsigned)ld + (unsigned)(k0 + logical * 8)) * 2u;
     } else {
-      int krow = ps * 16 + (tid >> 4);
+      int krow = ps * (NTH / CPR) + tid / CPR;
+      int pc = tid % CPR;
       int f = ((krow & 3) << 2) | ((krow >> 2) & 3);
-      int logical = (tid & 15) ^ f;
+      int logical = (pc & ~15) | ((pc & 15) ^ f);
       goff = ((unsigned)(k0 + krow) * (unsigned)ld + (unsigned)(r0 + logical * 8)) * 2u;
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + ps * 4096 + wid * 1024), 16, goff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + ps * (NTH * 16) + wid * 1024), 16, goff, 0, 0, 0);
   }
 }
 
 // ---- fragment reads --------------------------------------------------------------------------
 // returns the 8 halves op[row0 + (lane & 15)][ks*32 + 8*(lane >> 4) + j], j = 0..7
-template <bool KMAJ>
+template <bool KMAJ, int R>
 __device__ __forceinline__ h8 read_frag(const char* lds_tile, int row0, int ks, int lane) {
   if (KMAJ) {
     int row = row0 + (lane & 15);
@@ -79,8 +82,8 @@ __device__ __forceinline__ h8 read_frag(const char* lds_tile, int row0, int ks, 
     int c = (row0 >> 3) + (pp >> 1);
     int f0 = (q << 2) | ((2 * g) & 3);
     int f1 = (q << 2) | ((2 * g + 1) & 3);
-    const char* a0 = lds_tile + krow * 256 + ((c ^ f0) << 4) + 8 * (pp & 1);
-    const char* a1 = lds_tile + (krow + 4) * 256 + ((c ^ f1) << 4) + 8 * (pp & 1);
+    const char* a0 = lds_tile + krow * (R * 2) + (((c & ~15) | ((c & 15) ^ f0)) << 4) + 8 * (pp & 1);
+    const char* a1 = lds_tile + (krow + 4) * (R * 2) + (((c & ~15) | ((c & 15) ^ f1)) << 4) + 8 * (pp & 1);
     fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)LDS_PTR(a0));
     fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)LDS_PTR(a1));
     h8 r;
@@ -90,90 +93,17 @@ __device__ __forceinline__ h8 read_frag(const char* lds_tile, int row0, int ks, 
   }
 }
 
-template <bool AK, bool BK>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-
-  // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
-  // contiguous run of logical ids so neighbouring tiles (same A panel) hit the same L2.
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int ntn = (p.N + BN - 1) / BN;
-  const int ntm = (p.M + BM - 1) / BM;
-  const int ntiles = ntn * ntm;
-  const int split = lid / ntiles;
-  const int tile = lid - split * ntiles;
-  const int tm = tile / ntn, tn = tile - tm * ntn;
-
-  const int nkt = (p.K + BKT - 1) / BKT;
-  const int kt0 = split * p.ktps;
-  const int kt1 = min(nkt, kt0 + p.ktps);
-
-  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
-
-  f4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-  if (kt0 < kt1) {
-    stage_tile<AK>(ra, smem, wid, tid, tm * BM, kt0 * BKT, p.lda);
-    stage_tile<BK>(rb, smem + TILE_BYTES, wid, tid, tn * BN, kt0 * BKT, p.ldb);
-  }
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    char* sa = smem + cur * STAGE_BYTES;
-    char* sb = sa + TILE_BYTES;
-    if (kt + 1 < kt1) {
-      char* na = smem + (cur ^ 1) * STAGE_BYTES;
-      stage_tile<AK>(ra, na, wid, tid, tm * BM, (kt + 1) * BKT, p.lda);
-      stage_tile<BK>(rb, na + TILE_BYTES, wid, tid, tn * BN, (kt + 1) * BKT, p.ldb);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    h8 af[4][2], bf[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        af[i][ks] = read_frag<AK>(sa, wm * 64 + i * 16, ks, lane);
-        bf[i][ks] = read_frag<BK>(sb, wn * 64 + i * 16, ks, lane);
-      }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-  // ---- epilogue: lane owns C[m][n..n+3], m = (lane & 15), n = 4 * (lane >> 4) within each 16x16 tile
-  const int mrow = tm * BM + wm * 64 + (lane & 15);
-  const int ncol = tn * BN + wn * 64 + 4 * (lane >> 4);
+// ---- epilogue: lane owns C[m][n..n+3], m = (lane & 15), n = 4 * (lane >> 4) within each 16x16 tile
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, f4 (&acc)[MT][NT], int mrow, int ncol, int split) {
   if (p.splitk > 1) {
     float* ws = p.ws + (size_t)split * p.M * p.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       int m = mrow + i * 16;
       if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NT; ++j) {
         int n = ncol + j * 16;
         if (n < p.N) *reinterpret_cast<f4*>(ws + (size_t)m * p.N + n) = acc[i][j];
       }
@@ -182,11 +112,11 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   }
   const int flags = p.flags;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MT; ++i) {
     int m = mrow + i * 16;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NT; ++j) {
       int n = ncol + j * 16;
       if (n >= p.N) continue;
       f4 v = acc[i][j];
@@ -219,6 +149,196 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   }
 }
 
+// BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) = MT x NT MFMA tiles of 16x16.
+// Persistent: the grid is sized to the chip and every workgroup walks work items (output tile x K-split)
+// item, item + gridDim, ...  The LDS-DMA prefetch runs one K-tile ahead across item boundaries, so the
+// first tile of the next output tile is already in flight while this one's epilogue stores drain.
+template <bool AK, bool BK, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
+  constexpr int NTH = 64 * WM * WN;
+  constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
+  constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+
+  // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
+  // contiguous run of logical ids so neighbouring tiles (same A panel) hit the same L2.
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int ntm = (p.M + BM - 1) / BM;
+  const int ntiles = ntn * ntm;
+  const int nitems = ntiles * p.splitk;
+  const int nkt = (p.K + BKT - 1) / BKT;
+
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+
+  f4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int LOADS = (BM + BN) * 8 / NTH;   // LDS-DMA instructions per thread per K-tile
+  static_assert(LOADS == 8, "the counted vmcnt below assumes 8 loads per thread per tile");
+
+  // current position (item, kt) and the decoded tile of the item
+  int item = lid;
+  if (item >= nitems) return;
+  int split = item / ntiles, tile = item - split * ntiles;
+  int tm = tile / ntn, tn = tile - tm * ntn;
+  int kt = split * p.ktps, kt_end = min(nkt, kt + p.ktps);     // host guarantees kt < kt_end for every item
+  int buf = 0;
+  stage_tile<AK, BM, NTH>(ra, smem, wid, tid, tm * BM, kt * BKT, p.lda);
+  stage_tile<BK, BN, NTH>(rb, smem + A_BYTES, wid, tid, tn * BN, kt * BKT, p.ldb);
+
+  auto next_pos = [&](int& n_item, int& n_split, int& n_tm, int& n_tn, int& n_kt, int& n_end) {
+    n_item = item; n_split = split; n_tm = tm; n_tn = tn; n_kt = kt + 1; n_end = kt_end;
+    if (n_kt >= kt_end) {
+      n_item = item + nblk;
+      if (n_item < nitems) {
+        n_split = n_item / ntiles;
+        int t2 = n_item - n_split * ntiles;
+        n_tm = t2 / ntn; n_tn = t2 - n_tm * ntn;
+        n_kt = n_split * p.ktps; n_end = min(nkt, n_kt + p.ktps);
+      }
+    }
+  };
+  // VMEM stores this thread left in flight after an epilogue (0 = unknown / ragged tile: drain everything)
+  int pending_stores = 0;
+  auto finish_item = [&]() {
+    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+    pending_stores = !full ? 0 : ((p.splitk == 1 && (p.flags & EPI_QGELU) && p.aux_out) ? 2 * MT * NT : MT * NT);
+    epilogue<MT, NT>(p, acc, tm * BM + wm * (MT * 16) + (lane & 15), tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  if constexpr (MT == 8 && NT == 4) {
+    // ---- 256x256 tile, one workgroup per CU: the two waves of a SIMD must hide each other's load issue.
+    // One barrier per K-tile; the K-tile is cut into 4 stages of 16 MFMAs (k-step x row half).  Each stage
+    // first issues the LDS reads of the NEXT stage's fragments (and, in stages 0/1, the 4+4 LDS-DMA loads
+    // of the next K-tile into the other buffer), then runs its MFMA cluster on fragments already in
+    // registers.  The other buffer is free as soon as the top barrier is passed (every wave has finished
+    // the previous K-tile), so no second barrier is needed.
+    while (true) {
+      int n_item, n_split, n_tm, n_tn, n_kt, n_end;
+      next_pos(n_item, n_split, n_tm, n_tn, n_kt, n_end);
+      const bool has_next = n_item < nitems;
+      // This K-tile's LDS-DMA loads are OLDER than the previous item's epilogue stores, and vmcnt retires in
+      // issue order: a counted wait lets those stores keep draining under this tile's MFMAs.
+      if (pending_stores >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      else if (pending_stores == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pending_stores = 0;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* sa = smem + buf * STAGE_BYTES;
+      const char* sb = sa + A_BYTES;
+      char* na = smem + (buf ^ 1) * STAGE_BYTES;
+      const int arow = wm * 128, brow = wn * 64;
+      h8 bc[4], bn[4], ac[4], an[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bc[j] = read_frag<BK, BN>(sb, brow + j * 16, 0, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ac[i] = read_frag<AK, BM>(sa, arow + i * 16, 0, lane);
+      // stage 0: k-step 0, rows 0-63
+#pragma unroll
+      for (int i = 0; i < 4; ++i) an[i] = read_frag<AK, BM>(sa, arow + (4 + i) * 16, 0, lane);
+      if (has_next) stage_tile<AK, BM, NTH>(ra, na, wid, tid, n_tm * BM, n_kt * BKT, p.lda);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[j], ac[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // stage 1: k-step 0, rows 64-127
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ac[i] = read_frag<AK, BM>(sa, arow + i * 16, 1, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bn[j] = read_frag<BK, BN>(sb, brow + j * 16, 1, lane);
+      if (has_next) stage_tile<BK, BN, NTH>(rb, na + A_BYTES, wid, tid, n_tn * BN, n_kt * BKT, p.ldb);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[j], an[i], acc[4 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // stage 2: k-step 1, rows 0-63
+#pragma unroll
+      for (int i = 0; i < 4; ++i) an[i] = read_frag<AK, BM>(sa, arow + (4 + i) * 16, 1, lane);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[j], ac[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // stage 3: k-step 1, rows 64-127
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[j], an[i], acc[4 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 >= kt_end) finish_item();
+      if (!has_next) break;
+      item = n_item; split = n_split; tm = n_tm; tn = n_tn; kt = n_kt; kt_end = n_end;
+      buf ^= 1;
+    }
+  } else {
+    // ---- 128x128 tile, two workgroups per CU overlap each other: simple two-barrier loop
+    while (true) {
+      int n_item, n_split, n_tm, n_tn, n_kt, n_end;
+      next_pos(n_item, n_split, n_tm, n_tn, n_kt, n_end);
+      const bool has_next = n_item < nitems;
+      char* sa = smem + buf * STAGE_BYTES;
+      char* sb = sa + A_BYTES;
+      if (has_next) {
+        char* na = smem + (buf ^ 1) * STAGE_BYTES;
+        stage_tile<AK, BM, NTH>(ra, na, wid, tid, n_tm * BM, n_kt * BKT, p.lda);
+        stage_tile<BK, BN, NTH>(rb, na + A_BYTES, wid, tid, n_tn * BN, n_kt * BKT, p.ldb);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        h8 af[MT], bf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = read_frag<BK, BN>(sb, wn * (NT * 16) + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = read_frag<AK, BM>(sa, wm * (MT * 16) + i * 16, ks, lane);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 >= kt_end) finish_item();
+      if (!has_next) break;
+      item = n_item; split = n_split; tm = n_tm; tn = n_tn; kt = n_kt; kt_end = n_end;
+      buf ^= 1;
+    }
+  }
+}
+
 // out[m][n] = fp16( sum_s ws[s][m][n] )
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, half_t* __restrict__ C,
                                                             int M, int N, int ldc, int S) {
@@ -239,20 +359,56 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-int pick_splitk(int M, int N, int K) {
-  int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  int nkt = (K + BKT - 1) / BKT;
-  if (tiles >= 512 || nkt < 8) return 1;
-  int s = (1024 + tiles - 1) / tiles;           // aim at ~4 blocks per CU
-  if (s > nkt / 4) s = nkt / 4;
-  return s > 1 ? s : 1;
+struct TileCfg { int bm, bn, splitk; };
+
+// Large tower GEMMs take the 256x256 tile; anything that would leave most of a 256-wide tile empty, or
+// that cannot fill the chip with 256x256 tiles even after splitting K, takes 128x128.
+TileCfg pick_cfg(int M, int N, int K, bool allow_split) {
+  const int nkt = (K + BKT - 1) / BKT;
+  auto tiles_of = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  TileCfg c;
+  bool big = (M % 256 == 0 || M >= 2048) && (N % 256 == 0 || N >= 2048) && M >= 256 && N >= 256;
+  if (big) {
+    long t = tiles_of(256, 256);
+    long reach = allow_split ? t * (nkt / 8 > 0 ? nkt / 8 : 1) : t;
+    if (reach < 192) big = false;            // cannot occupy most of the 256 CUs
+  }
+  c.bm = c.bn = big ? 256 : 128;
+  c.splitk = 1;
+  if (allow_split) {
+    long t = tiles_of(c.bm, c.bn);
+    long target = big ? 512 : 1024;          // blocks in flight: 2 resp. 4 per CU
+    if (t < target / 2 && nkt >= 8) {
+      long s = (target + t - 1) / t;
+      if (s > nkt / 4) s = nkt / 4;
+      c.splitk = (int)(s > 1 ? s : 1);
+    }
+  }
+  return c;
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stream) {
+  constexpr int SMEM = 2 * (BM + BN) * BKT * 2;
+  dim3 block(64 * WM * WN);
+  if (SMEM > 64 * 1024) {
+    static bool once = (hmmc_allow_lds((const void*)gemm_f16_kernel<true, true, BM, BN, WM, WN>, SMEM),
+                        hmmc_allow_lds((const void*)gemm_f16_kernel<true, false, BM, BN, WM, WN>, SMEM),
+                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, true, BM, BN, WM, WN>, SMEM),
+                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, false, BM, BN, WM, WN>, SMEM), true);
+    (void)once;
+  }
+  if (ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<true, true, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_f16_kernel<true, false, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
+  else if (!ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<false, true, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
+  else hipLaunchKernelGGL((gemm_f16_kernel<false, false, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
 }
 
 }  // namespace
 
 extern "C" size_t hmmc_gemm_f16_workspace(int M, int N, int K) {
-  int s = pick_splitk(M, N, K);
-  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+  TileCfg c = pick_cfg(M, N, K, true);
+  return c.splitk > 1 ? (size_t)c.splitk * M * N * sizeof(float) : 0;
 }
 
 extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -269,8 +425,8 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
   // extents of the operand buffers (bytes); 32-bit buffer offsets
   uint64_t a_bytes = a_kmajor ? ((uint64_t)(M - 1) * lda + K) * 2 : ((uint64_t)(K - 1) * lda + M) * 2;
   uint64_t b_bytes = b_kmajor ? ((uint64_t)(N - 1) * ldb + K) * 2 : ((uint64_t)(K - 1) * ldb + N) * 2;
-  uint64_t a_reach = a_kmajor ? (uint64_t)(M + BM) * lda * 2 : (uint64_t)(K + BKT) * lda * 2;
-  uint64_t b_reach = b_kmajor ? (uint64_t)(N + BN) * ldb * 2 : (uint64_t)(K + BKT) * ldb * 2;
+  uint64_t a_reach = a_kmajor ? (uint64_t)(M + 256) * lda * 2 : (uint64_t)(K + BKT) * lda * 2;
+  uint64_t b_reach = b_kmajor ? (uint64_t)(N + 256) * ldb * 2 : (uint64_t)(K + BKT) * ldb * 2;
   if (a_reach >= (1ull << 32) || b_reach >= (1ull << 32) || a_bytes >= (1ull << 31) || b_bytes >= (1ull << 31))
     return HMMC_ERR_UNSUPPORTED;
 
@@ -281,17 +437,24 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.flags = epilogue;
   p.a_bytes = (unsigned)a_bytes; p.b_bytes = (unsigned)b_bytes;
   int nkt = (K + BKT - 1) / BKT;
-  int splitk = epilogue ? 1 : pick_splitk(M, N, K);
+  TileCfg cfg = pick_cfg(M, N, K, epilogue == 0);
+  int splitk = cfg.splitk;
   if (splitk > 1 && (!workspace || ws_bytes < (size_t)splitk * M * N * sizeof(float))) splitk = 1;
-  p.splitk = splitk;
   p.ktps = (nkt + splitk - 1) / splitk;
+  splitk = (nkt + p.ktps - 1) / p.ktps;        // every split owns at least one K-tile
+  p.splitk = splitk;
   p.ws = (float*)workspace;
-  int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  dim3 grid(tiles * splitk), block(256);
-  if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f16_kernel<true, true>), grid, block, SMEM_BYTES, stream, p);
-  else if (a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f16_kernel<true, false>), grid, block, SMEM_BYTES, stream, p);
-  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f16_kernel<false, true>), grid, block, SMEM_BYTES, stream, p);
-  else hipLaunchKernelGGL((gemm_f16_kernel<false, false>), grid, block, SMEM_BYTES, stream, p);
+  long tiles = (long)((M + cfg.bm - 1) / cfg.bm) * ((N + cfg.bn - 1) / cfg.bn);
+  long items = tiles * splitk;
+  static const int num_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  long resident = (long)num_cu * (cfg.bm == 256 ? 1 : 2);       // workgroups the LDS budget keeps resident
+  dim3 grid((unsigned)(items < resident ? items : resident));
+  if (cfg.bm == 256) launch_cfg<256, 256, 2, 4>(p, a_kmajor, b_kmajor, grid, stream);
+  else launch_cfg<128, 128, 2, 2>(p, a_kmajor, b_kmajor, grid, stream);
   if (splitk > 1) {
     size_t nb = ((size_t)M * N / 4 + 255) / 256;
     int blocks = (int)(nb < 2048 ? nb : 2048);

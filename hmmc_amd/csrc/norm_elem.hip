@@ -158,53 +158,77 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-// out[col] = sum_b partial[b][which][col]
-__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int nblocks, int D) {
-  int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= D) return;
-  float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblocks; ++k) {
-    a += partial[((long)k * 2) * D + col];
-    b += partial[((long)k * 2 + 1) * D + col];
+// out[col] = sum_r partial[r][col] for an fp32 [R][N] partial matrix.  32 columns x 8 row-lanes per block:
+// each row-lane streams 128-byte row segments, the 8 lanes are combined through LDS (fixed order, so the
+// result is deterministic).  Columns < split go to out0, the rest to out1 (LayerNorm: dgamma | dbeta).
+template <typename TO>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ partial, TO* __restrict__ out0,
+                                                        TO* __restrict__ out1, int R, int N, int split, int round_f16) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < N) {
+    int r = rl;
+    for (; r + 8 < R; r += 16) {
+      a0 += partial[(long)r * N + col];
+      a1 += partial[(long)(r + 8) * N + col];
+    }
+    if (r < R) a0 += partial[(long)r * N + col];
   }
-  dgamma[col] = a;
-  dbeta[col] = b;
+  red[rl][c] = a0 + a1;
+  __syncthreads();
+  if (rl == 0 && col < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    if (round_f16) t = r16(t);
+    if (col < split) out0[col] = (TO)t;
+    else out1[col - split] = (TO)t;
+  }
 }
 
 // ---- column sums: out[n] = sum_m X[m][n]  (two stages, fp32 partials) ---------------------------
+// stage 1: block = 32 chunks (16 B each) x 8 row-lanes over a slab of rows; partial[slab][N]
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, float* __restrict__ partial,
                                                              int M, int N, long ld, int rows_per_block) {
   constexpr int VN = Vec<T>::N;
   typedef typename Vec<T>::type V;
-  // blockIdx.x: column group of 256 chunks; blockIdx.y: row block
-  const int chunk = blockIdx.x * 256 + threadIdx.x;
-  const int col = chunk * VN;
-  if (col >= N) return;
+  __shared__ float red[8][32 * VN + 1];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cl) * VN;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   float acc[VN];
 #pragma unroll
   for (int j = 0; j < VN; ++j) acc[j] = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    V t = *reinterpret_cast<const V*>(X + (long)r * ld + col);
+  if (col < N) {
+    int r = r0 + rl;
+    for (; r + 8 < r1; r += 16) {
+      V t0 = *reinterpret_cast<const V*>(X + (long)r * ld + col);
+      V t1 = *reinterpret_cast<const V*>(X + (long)(r + 8) * ld + col);
 #pragma unroll
-    for (int j = 0; j < VN; ++j) acc[j] += (float)t[j];
+      for (int j = 0; j < VN; ++j) acc[j] += (float)t0[j] + (float)t1[j];
+    }
+    if (r < r1) {
+      V t0 = *reinterpret_cast<const V*>(X + (long)r * ld + col);
+#pragma unroll
+      for (int j = 0; j < VN; ++j) acc[j] += (float)t0[j];
+    }
   }
 #pragma unroll
-  for (int j = 0; j < VN; ++j) partial[(long)blockIdx.y * N + col + j] = acc[j];
-}
-
-template <typename TO>
-__global__ void colsum_final_kernel(const float* __restrict__ partial, TO* __restrict__ out, int nblocks, int N,
-                                    int round_f16) {
-  int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
-  float a = 0.f;
-  for (int k = 0; k < nblocks; ++k) a += partial[(long)k * N + col];
-  if (round_f16) a = r16(a);
-  out[col] = (TO)a;
+  for (int j = 0; j < VN; ++j) red[rl][cl * VN + j] = acc[j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * VN; i += 256) {
+    int cc = blockIdx.x * 32 * VN + i;
+    if (cc < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k][i];
+      partial[(long)blockIdx.y * N + cc] = t;
+    }
+  }
 }
 
 // ---- patch extraction (im2col of the stride=patch conv), fp32 NCHW -> fp16 [N*L, 3*p*p] ---------
@@ -327,7 +351,7 @@ extern "C" int hmmc_layernorm_fwd(const void* x, const float* gamma, const float
 
 extern "C" size_t hmmc_layernorm_bwd_workspace(int rows, int D) {
   int nb = (rows + 3) / 4;
-  if (nb > 512) nb = 512;
+  if (nb > 1024) nb = 1024;
   return (size_t)nb * 2 * D * sizeof(float);
 }
 
@@ -339,7 +363,7 @@ extern "C" int hmmc_layernorm_bwd(const void* dy, const void* x, const float* ga
   int vn = dtype == 0 ? 8 : 4;
   if (D % vn || D > LN_MAXD || in_stride % vn) return HMMC_ERR_UNSUPPORTED;
   int nb = (rows + 3) / 4;
-  if (nb > 512) nb = 512;
+  if (nb > 1024) nb = 1024;
   if (!workspace || ws_bytes < (size_t)nb * 2 * D * sizeof(float)) return HMMC_ERR_WORKSPACE;
   float* partial = (float*)workspace;
   if (dtype == 0)
@@ -348,16 +372,18 @@ extern "C" int hmmc_layernorm_bwd(const void* dy, const void* x, const float* ga
   else
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)dy, (const float*)x, gamma, mean,
                        rstd, (const float*)dres, (float*)dx, partial, row_index, rows, D, in_stride);
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)partial, dgamma,
-                     dbeta, nb, D);
+  hipLaunchKernelGGL(colreduce_kernel<float>, dim3((2 * D + 31) / 32), dim3(256), 0, stream, (const float*)partial, dgamma,
+                     dbeta, nb, 2 * D, D, 0);
   return hmmc_launch_status();
 }
 
-extern "C" size_t hmmc_colsum_workspace(int M, int N) {
-  int rb = (M + 255) / 256;
-  if (rb > 256) rb = 256;
-  return (size_t)rb * N * sizeof(float);
+static inline int colsum_slabs(int M) {
+  int rb = (M + 63) / 64;              // >= 64 rows per slab
+  if (rb > 1024) rb = 1024;
+  return rb < 1 ? 1 : rb;
 }
+
+extern "C" size_t hmmc_colsum_workspace(int M, int N) { return (size_t)colsum_slabs(M) * N * sizeof(float); }
 
 // out[n] = sum_m X[m][n]; in_dtype/out_dtype: 0 fp16, 1 fp32; round_f16: round the fp32 sum to fp16 first
 extern "C" int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int in_dtype, int out_dtype, int round_f16,
@@ -365,12 +391,11 @@ extern "C" int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int 
   if (!X || !out || M <= 0 || N <= 0) return HMMC_ERR_ARG;
   int vn = in_dtype == 0 ? 8 : 4;
   if (N % vn || ld % vn) return HMMC_ERR_UNSUPPORTED;
-  int rb = (M + 255) / 256;
-  if (rb > 256) rb = 256;
+  int rb = colsum_slabs(M);
   int rpb = (M + rb - 1) / rb;
   rb = (M + rpb - 1) / rpb;
   if (!workspace || ws_bytes < (size_t)rb * N * sizeof(float)) return HMMC_ERR_WORKSPACE;
-  dim3 grid((N / vn + 255) / 256, rb);
+  dim3 grid((N / vn + 31) / 32, rb);
   if (in_dtype == 0)
     hipLaunchKernelGGL(colsum_partial_kernel<half_t>, grid, dim3(256), 0, stream, (const half_t*)X, (float*)workspace, M, N,
                        ld, rpb);
@@ -378,11 +403,11 @@ extern "C" int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int 
     hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, (float*)workspace, M, N, ld,
                        rpb);
   if (out_dtype == 0)
-    hipLaunchKernelGGL(colsum_final_kernel<half_t>, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace,
-                       (half_t*)out, rb, N, round_f16);
+    hipLaunchKernelGGL(colreduce_kernel<half_t>, dim3((N + 31) / 32), dim3(256), 0, stream, (const float*)workspace,
+                       (half_t*)out, (half_t*)out, rb, N, N, round_f16);
   else
-    hipLaunchKernelGGL(colsum_final_kernel<float>, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace,
-                       (float*)out, rb, N, round_f16);
+    hipLaunchKernelGGL(colreduce_kernel<float>, dim3((N + 31) / 32), dim3(256), 0, stream, (const float*)workspace,
+                       (float*)out, (float*)out, rb, N, N, round_f16);
   return hmmc_launch_status();
 }
 

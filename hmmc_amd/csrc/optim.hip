@@ -9,13 +9,20 @@
 // tensor op), so fp16 results are bit-identical to the reference expression.
 //
 // tab  : int64 [T][8]  = { p, g, m, v (device pointers), numel, dtype (0 fp16 / 1 fp32), 0, 0 }
-// ftab : float [T][8]  = { lr_scheduled, weight_decay, b1, b2, eps, max_grad_norm, 0, 0 }
+// ftab : float [T][8]  = { lr_scheduled, weight_decay, b1, b2, eps, max_grad_norm, 1-b1, 1-b2 }
 // chunk: int32 [C][2]  = { tensor index, chunk index }   (CHUNK elements per block)
 #include "common.h"
 
 namespace {
 
 constexpr int CHUNK = 32768;
+
+// The reference evaluates every fp16 tensor op as: fp32 arithmetic, round to fp32, then round to fp16.
+// hipcc would fuse "multiply, convert" into v_fma_mixlo_f16 (ONE rounding from the exact product) and
+// contract separate mul/add into fma; both differ from the reference in the last fp16 bit on ties.
+// opq() makes a value opaque to the optimizer, pinning an fp32 rounding point.
+__device__ __forceinline__ float opq(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ float r16s(float x) { return (float)(half_t)opq(x); }
 
 __device__ __forceinline__ float block_sum(float v) {
   __shared__ float red[4];
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void mt_scale_kernel(const long* __restrict__ 
   const long i0 = (long)ci * CHUNK, i1 = min(n, i0 + CHUNK);
   if (e[5] == 0) {
     half_t* g = reinterpret_cast<half_t*>(e[1]);
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) g[i] = (half_t)((float)g[i] * c);
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) g[i] = (half_t)opq((float)g[i] * c);
   } else {
     float* g = reinterpret_cast<float*>(e[1]);
     for (long i = i0 + threadIdx.x; i < i1; i += 256) g[i] = g[i] * c;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict
   const long n = e[4];
   const long i0 = (long)ci * CHUNK, i1 = min(n, i0 + CHUNK);
   const float lr = f[0], wd = f[1], b1 = f[2], b2 = f[3], eps = f[4], maxn = f[5];
-  const float ob1 = (float)(1.0 - (double)b1), ob2 = (float)(1.0 - (double)b2);
+  const float ob1 = f[6], ob2 = f[7];     // 1-b1, 1-b2 evaluated in double on the host, as the reference does
   if (e[5] == 0) {
     half_t* p = reinterpret_cast<half_t*>(e[0]);
     half_t* g = reinterpret_cast<half_t*>(e[1]);
@@ -107,15 +114,15 @@ __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict
     }
     for (long i = i0 + threadIdx.x; i < i1; i += 256) {
       float gi = (float)g[i];
-      if (maxn > 0.f) { gi = r16(gi * c); g[i] = (half_t)gi; }
+      if (maxn > 0.f) { gi = r16s(gi * c); g[i] = (half_t)gi; }
       // add_(g, alpha) is a true fma on the reference's CPU path; addcmul_ is (value*g)*g then an add
-      float mi = r16(__fmaf_rn(ob1h, gi, r16((float)m[i] * b1)));
-      float vi = r16(__fadd_rn(r16((float)v[i] * b2), __fmul_rn(__fmul_rn(ob2, gi), gi)));
+      float mi = r16s(__fmaf_rn(ob1h, gi, r16s((float)m[i] * b1)));
+      float vi = r16s(r16s((float)v[i] * b2) + opq(opq(ob2 * gi) * gi));
       float pi = (float)p[i];
-      float u = r16(mi / r16(r16(sqrtf(vi)) + eps));
-      if (wd > 0.f) u = r16(u + r16(wd * pi));
-      float uw = r16(lr * u);
-      p[i] = (half_t)(pi - uw);
+      float u = r16s(mi / r16s(r16s(sqrtf(vi)) + eps));
+      if (wd > 0.f) u = r16s(u + r16s(wd * pi));
+      float uw = r16s(lr * u);
+      p[i] = (half_t)opq(pi - uw);
       m[i] = (half_t)mi;
       v[i] = (half_t)vi;
     }
@@ -132,11 +139,11 @@ __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict
     for (long i = i0 + threadIdx.x; i < i1; i += 256) {
       float gi = g[i];
       if (maxn > 0.f) { gi = gi * c; g[i] = gi; }
-      float mi = __fmaf_rn(ob1, gi, __fmul_rn(m[i], b1));
-      float vi = __fadd_rn(__fmul_rn(v[i], b2), __fmul_rn(__fmul_rn(ob2, gi), gi));
-      float u = __fdiv_rn(mi, __fadd_rn(__fsqrt_rn(vi), eps));
-      if (wd > 0.f) u = __fadd_rn(u, __fmul_rn(wd, p[i]));
-      p[i] = __fsub_rn(p[i], __fmul_rn(lr, u));
+      float mi = __fmaf_rn(ob1, gi, opq(m[i] * b1));
+      float vi = opq(v[i] * b2) + opq(opq(ob2 * gi) * gi);
+      float u = mi / opq(sqrtf(vi) + eps);
+      if (wd > 0.f) u = opq(u) + opq(wd * p[i]);
+      p[i] = p[i] - opq(lr * opq(u));
       m[i] = mi;
       v[i] = vi;
     }
@@ -154,13 +161,13 @@ __global__ __launch_bounds__(256) void mt_ema_kernel(const long* __restrict__ ta
     half_t* pk = reinterpret_cast<half_t*>(e[0]);
     const half_t* p = reinterpret_cast<const half_t*>(e[1]);
     for (long i = i0 + threadIdx.x; i < i1; i += 256)
-      pk[i] = (half_t)(r16((float)pk[i] * mom) + r16((float)p[i] * one_minus));
+      pk[i] = (half_t)opq(r16s((float)pk[i] * mom) + r16s((float)p[i] * one_minus));
   } else {
     float* pk = reinterpret_cast<float*>(e[0]);
     const float* p = reinterpret_cast<const float*>(e[1]);
     for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-      float a = __fmul_rn(pk[i], mom), b = __fmul_rn(p[i], one_minus);   // three tensor ops, no fma contraction
-      pk[i] = __fadd_rn(a, b);
+      float a = opq(pk[i] * mom), b = opq(p[i] * one_minus);   // three tensor ops, no fma contraction
+      pk[i] = a + b;
     }
   }
 }

@@ -160,7 +160,8 @@ class BertAdam(Optimizer):
                 dev = p.device
                 rows.append((p.data_ptr(), p.grad.data_ptr(), state["next_m"].data_ptr(), state["next_v"].data_ptr(),
                              p.numel(), _dtype_flag(p)))
-                frows.append((lr_s, group["weight_decay"], group["b1"], group["b2"], group["e"], group["max_grad_norm"], 0.0, 0.0))
+                frows.append((lr_s, group["weight_decay"], group["b1"], group["b2"], group["e"], group["max_grad_norm"],
+                              1 - group["b1"], 1 - group["b2"]))
                 state["step"] += 1
         if not rows:
             return loss

@@ -129,7 +129,7 @@ int hmmc_temporal_attention_bwd(const float* qkv, const float* probs, const floa
                                 hmmc_stream_t stream);
 
 /* Multi-tensor kernels.  tab: int64 [T][8] = {p, g, m, v device pointers, numel, dtype (0 fp16, 1 fp32), 0, 0};
- * ftab: float [T][8] = {scheduled lr, weight_decay, b1, b2, eps, max_grad_norm, 0, 0};
+ * ftab: float [T][8] = {scheduled lr, weight_decay, b1, b2, eps, max_grad_norm, 1-b1, 1-b2};
  * chunk: int32 [nchunks][2] = {tensor index, chunk index}, hmmc_mt_chunk_elems() elements per chunk;
  * sumsq: float [T] scratch. */
 int hmmc_mt_chunk_elems(void);

@@ -215,7 +215,7 @@ def fx_enc_b32(mclip, mmodel, mopt, mmetrics):
 def fx_bertadam(mclip, mmodel, mopt, mmetrics):
     out = {}
     specs = [("a32", (37,), torch.float32, 0.2, 1e-4, 3.0), ("b32", (8, 9), torch.float32, 0.0, 3e-5, 0.01),
-             ("c16", (64,), torch.float16, 0.2, 1e-4, 2.0), ("d16", (5, 16), torch.float16, 0.0, 1e-7, 0.05)]
+             ("c16", (64,), torch.float16, 0.2, 1e-4, 2.0), ("d16", (4, 32), torch.float16, 0.0, 1e-7, 0.05)]
     params, groups = [], []
     for name, shape, dt, wd, lr, gscale in specs:
         p = torch.nn.Parameter(synth.normal(f"bertadam.{name}.p", shape, 0.5).to(dt))

@@ -57,6 +57,26 @@ def test_gemm_mm_wgrad_exact_integers(T, N, K):
     assert torch.equal(c.float(), ref), f"max diff {(c.float()-ref).abs().max()}"
 
 
+@pytest.mark.parametrize("layout,M,N,K", [("kk", 16384, 768, 768), ("kk", 20000, 2304, 768), ("km", 16384, 768, 2304),
+                                          ("mm", 768, 768, 12800), ("mm", 3072, 768, 25000)])
+def test_gemm_big_tile_exact_integers(layout, M, N, K):
+    """Shapes that select the 256x256 / 8-wave configuration (and split-K for the weight-gradient layout)."""
+    if layout == "kk":
+        a, b = ints(M, K, lo=-1, hi=2), ints(N, K, lo=-1, hi=2, seed=1)
+        c = ops.gemm_f16(a, b, M, N, K)
+        ref = a.float() @ b.float().t()
+    elif layout == "km":
+        a, b = ints(M, K, lo=-1, hi=2), ints(K, N, lo=-1, hi=2, seed=1)
+        c = ops.gemm_f16(a, b, M, N, K, a_kmajor=True, b_kmajor=False)
+        ref = a.float() @ b.float()
+    else:
+        a, b = ints(K, M, lo=-1, hi=2), ints(K, N, lo=-1, hi=2, seed=1)
+        c = ops.gemm_f16(a, b, M, N, K, a_kmajor=False, b_kmajor=False)
+        ref = a.float().t() @ b.float()
+    assert float(ref.abs().max()) <= 2048
+    assert torch.equal(c.float(), ref), f"max diff {(c.float()-ref).abs().max()}"
+
+
 def test_gemm_random_and_epilogues():
     M, N, K = 1000, 384, 256
     a, w = rnd(M, K, scale=0.5), rnd(N, K, scale=0.1, seed=1)

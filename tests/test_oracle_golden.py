@@ -104,3 +104,67 @@ def test_encoders_and_loss(name, mode, dims, use_temp):
         tg = sd["text_encoder.token_embedding.weight"].grad
         close(tg[synth.SOT, :8], g["g:text_encoder.token_embedding.weight[SOT]"], 1e-6, 2e-3, "tok SOT")
         close(tg[synth.EOT, :8], g["g:text_encoder.token_embedding.weight[EOT]"], 1e-6, 2e-3, "tok EOT")
+
+
+BERTADAM_SPECS = [("a32", (37,), torch.float32, 0.2, 1e-4, 3.0), ("b32", (8, 9), torch.float32, 0.0, 3e-5, 0.01),
+                  ("c16", (64,), torch.float16, 0.2, 1e-4, 2.0), ("d16", (4, 32), torch.float16, 0.0, 1e-7, 0.05)]
+
+
+def test_bertadam_bit_exact():
+    """BertAdam.step op by op in each tensor's dtype.  fp16 tensors are sized as multiples of the CPU vector
+    width: torch's CPU kernels round differently in their scalar tail loop (Half arithmetic) than in the
+    vectorised body (float arithmetic), an artefact of the host library, not of the reference's algorithm."""
+    g = golden("bertadam")
+    for name, shape, dt, wd, lr, gs in BERTADAM_SPECS:
+        p = synth.normal(f"bertadam.{name}.p", shape, 0.5).to(dt)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for step in range(5):
+            gr = synth.normal(f"bertadam.{name}.g{step}", shape, gs).to(dt)
+            p, m, v, gc = O.bert_adam_step(p, gr, m, v, step, lr, 20, 0.1, wd)
+            for nm, mine in (("g", gc), ("m", m), ("v", v), ("p", p)):
+                ref = t(g[f"{name}.{nm}{step}"])
+                assert torch.equal(mine.float(), ref), f"{name}.{nm}{step} differs from the reference"
+    close(g["lr1"], [1e-4 * O.warmup_cosine(2 / 20, 0.1) * s for s in (1, 0.3, 1, 1e-3)], 1e-12, what="lr")  # get_lr() reads the already incremented step
+
+
+def _groups(names, lr, text_lr, coef_lr, wd):
+    """main_task_retrieval.py:171-205: (lr, weight_decay) per parameter name."""
+    out = {}
+    for n in names:
+        nod = any(nd in n for nd in ("bias", "LayerNorm.bias", "LayerNorm.weight"))
+        if "visual_encoder.visual." in n:
+            l = lr * coef_lr
+        elif "text_encoder." in n:
+            l = text_lr
+        else:
+            l = lr
+        out[n] = (l, 0.0 if nod else wd)
+    return out
+
+
+def test_train_steps_fp32():
+    """4 steps of forward / backward / clip_grad_norm_(1.0) / BertAdam (main_task_retrieval.py:272-302)."""
+    g = golden("train_ft_fp32")
+    sd = {k: v.requires_grad_(v.is_floating_point()) for k, v in synth.finetune_state(synth.TINY).items()}
+    names = [k for k, v in sd.items() if v.requires_grad]
+    hp = _groups(names, 2e-3, 1e-3, 0.5, 0.2)
+    state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in names}
+    for step in range(4):
+        ids, mask, vid, vf, idx = synth.finetune_batch(4, 4, 32, tag=f"train_ft.s{step}")
+        for k in names:
+            sd[k].grad = None
+        loss, _ = O.finetune_loss(ids, vid, sd, mode="fp32")
+        loss.backward()
+        tn = torch.nn.utils.clip_grad_norm_([sd[k] for k in names], 1.0)
+        with torch.no_grad():
+            for k in names:
+                m, v = state[k]
+                p, m, v, _ = O.bert_adam_step(sd[k].data, sd[k].grad, m, v, step, hp[k][0], 10, 0.1, hp[k][1])
+                sd[k].data.copy_(p)
+                state[k] = (m, v)
+        close(loss.detach(), g[f"loss{step}"], 2e-3, what=f"loss{step}")
+        close(tn, g[f"gnorm{step}"], 0, 5e-3, f"gnorm{step}")
+        if step < 2:
+            for key in g.files:
+                if key.startswith(f"p{step}:"):
+                    close(sd[key.split(":", 1)[1]].detach().reshape(-1)[:16], g[key], 2e-4, 1e-3, key)
