@@ -48,6 +48,19 @@ SIGNATURES = {
     "hmmc_mt_bertadam": ("pppipip", "i"),
     "hmmc_mt_ema": ("ppiffp", "i"),
     "hmmc_enqueue": ("ppiillp", "i"),
+    "hmmc_bn_workspace": ("ii", "z"),
+    "hmmc_bn_stats": ("ppiipzp", "i"),
+    "hmmc_bn_apply_relu": ("ppppppli p".replace(" ", ""), "i"),
+    "hmmc_bn_bwd_reduce": ("ppppppiipzp", "i"),
+    "hmmc_bn_bwd_apply": ("pppppppplifp", "i"),
+    "hmmc_rowdot": ("pppiip", "i"),
+    "hmmc_moco_loss_fwd": ("pppppilffp", "i"),
+    "hmmc_moco_loss_bwd": ("pppppilffp", "i"),
+    "hmmc_row_axpy": ("ppplip", "i"),
+    "hmmc_gelu_erf_fwd": ("pplp", "i"),
+    "hmmc_gelu_erf_bwd": ("ppplp", "i"),
+    "hmmc_ce_fwd": ("ppppppilp", "i"),
+    "hmmc_ce_bwd": ("pppppilp", "i"),
 }
 
 ERRORS = {-1: "invalid argument", -2: "unsupported shape/alignment", -3: "workspace too small", -4: "kernel launch failed"}

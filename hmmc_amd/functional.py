@@ -283,3 +283,123 @@ class FinetuneHeadFn(torch.autograd.Function):
         dv = ops.l2norm_bwd(dkeys[:B], keys[:B], vnorm)
         du = ops.l2norm_bwd(dkeys[B:], keys[B:], unorm).view(B, F, E) if F else None
         return dq, dv, du, None, None, None
+
+
+# ----------------------------------------------------------------------------- pre-training (MoCo) stages
+
+def _sync_sum(t):
+    """Sum a small statistics tensor over ranks (SyncBatchNorm's exchange, modules/modeling.py:115-129)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = t.contiguous()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+class MlpFn(torch.autograd.Function):
+    """Linear(512,4096) -> BatchNorm1d (batch statistics over all ranks' rows) -> ReLU -> Linear(4096,512)
+    (reference MLP, modules/modeling.py:788-807).  Returns (y, batch_mean, batch_var_biased, n_rows_global)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, gamma, beta, w2, b2, eps):
+        x = x.contiguous()
+        h = ops.linear_f32(x, w1, bias=b1)
+        sums = ops.bn_stats(h)
+        n_local = torch.tensor([float(h.shape[0])], device=h.device)
+        packed = _sync_sum(torch.cat([sums.view(-1), n_local]))
+        n = packed[-1]
+        mean = packed[:h.shape[1]] / n
+        var = (packed[h.shape[1]:-1] / n - mean * mean).clamp_min(0.0)
+        rstd = torch.rsqrt(var + eps)
+        y = ops.bn_apply_relu(h, mean.contiguous(), rstd.contiguous(), gamma, beta)
+        out = ops.linear_f32(y, w2, bias=b2)
+        ctx.save_for_backward(x, w1, gamma, w2, h, y, mean, rstd, n)
+        ctx.mark_non_differentiable(mean, var, n)
+        return out, mean, var, n
+
+    @staticmethod
+    def backward(ctx, dout, _dm, _dv, _dn):
+        x, w1, gamma, w2, h, y, mean, rstd, n = ctx.saved_tensors
+        dout = dout.contiguous()
+        dw2 = ops.wgrad_f32(dout, y)
+        db2 = ops.colsum(dout)
+        dy = ops.dgrad_f32(dout, w2)
+        local = ops.bn_bwd_reduce(dy, y, h, mean, rstd)
+        # dgamma / dbeta are this rank's sums (DDP averages parameter gradients afterwards, as with SyncBatchNorm);
+        # dx needs the sums over every rank's rows
+        dbeta, dgamma = local[0].clone(), local[1].clone()
+        sums = _sync_sum(local.clone()) if _world() > 1 else local
+        dh = ops.bn_bwd_apply(dy, y, h, mean, rstd, gamma, sums, n_global=float(n))
+        dw1 = ops.wgrad_f32(dh, x)
+        db1 = ops.colsum(dh)
+        dx = ops.dgrad_f32(dh, w1)
+        return dx, dw1, db1, dgamma, dbeta, dw2, db2, None
+
+
+def _world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class MocoLossFn(torch.autograd.Function):
+    """sum over rows of w * CE([q.k, q.queue]/T, label 0) with q, k L2-normalised (F.normalize, eps 1e-12):
+    contrastive_loss of modules/modeling.py:286-313 for R stacked (q, k) pairs that share one queue.
+    k and the queue receive no gradient (keys come from the momentum encoders under no_grad)."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue, temperature, w):
+        q, k = q.contiguous(), k.contiguous()
+        R, E = q.shape
+        Kq = queue.shape[1]
+        qn, qnorm = ops.l2norm_fwd(q, eps=1e-12)
+        kn, _ = ops.l2norm_fwd(k, eps=1e-12)
+        lpos = ops.rowdot(qn, kn)
+        S = ops.gemm_f32(qn, queue, R, Kq, E, (E, 1), (Kq, 1))
+        loss, lse = ops.moco_loss_fwd(S, lpos, temperature, w)
+        ctx.save_for_backward(qn, qnorm, kn, lpos, S, lse, queue)
+        ctx.cfg = (temperature, w)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        qn, qnorm, kn, lpos, S, lse, queue = ctx.saved_tensors
+        temperature, w = ctx.cfg
+        R, E = qn.shape
+        Kq = queue.shape[1]
+        dlpos = ops.moco_loss_bwd_(S, lpos, lse, gout, temperature, w)       # S now holds dS
+        dqn = ops.gemm_f32(S, queue, R, E, Kq, (Kq, 1), (1, Kq))             # dS @ queue^T
+        ops.row_axpy_(dqn, dlpos, kn)
+        dq = ops.l2norm_bwd(dqn, qn, qnorm)
+        return dq, None, None, None, None
+
+
+class MlmHeadFn(torch.autograd.Function):
+    """BertLMPredictionHead + cross-entropy with ignore_index -100 (modules/module_cross.py:308-357,
+    modules/modeling.py:171-179): dense, erf-GELU, TF-LayerNorm(1e-12), decoder to the vocabulary, mean CE."""
+
+    @staticmethod
+    def forward(ctx, hidden, labels, dw, db, lnw, lnb, decw, decb):
+        x = hidden.contiguous().view(-1, hidden.shape[-1])
+        labels = labels.contiguous().view(-1)
+        a = ops.linear_f32(x, dw, bias=db)
+        g = ops.gelu_erf_fwd(a)
+        t, mean, rstd = ops.layernorm_fwd(g, lnw, lnb, 1e-12)
+        logits = ops.linear_f32(t, decw, bias=decb)
+        loss_sum, lse, count = ops.ce_fwd(logits, labels)
+        ctx.save_for_backward(x, labels, dw, lnw, decw, a, g, t, mean, rstd, logits, lse, count)
+        ctx.shape = hidden.shape
+        return loss_sum / count.clamp(min=1.0)[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, labels, dw, lnw, decw, a, g, t, mean, rstd, logits, lse, count = ctx.saved_tensors
+        dlogits = ops.ce_bwd_(logits, labels, lse, gout, count)
+        d_decw = ops.wgrad_f32(dlogits, t)
+        d_decb = ops.colsum(dlogits)
+        dt = ops.dgrad_f32(dlogits, decw)
+        dg, d_lnw, d_lnb = ops.layernorm_bwd(dt, g, lnw, mean, rstd)
+        da = ops.gelu_erf_bwd(a, dg)
+        d_dw = ops.wgrad_f32(da, x)
+        d_db = ops.colsum(da)
+        dx = ops.dgrad_f32(da, dw)
+        return dx.view(ctx.shape), None, d_dw, d_db, d_lnw, d_lnb, d_decw, d_decb

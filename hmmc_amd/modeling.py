@@ -96,7 +96,211 @@ class CLIP4ClipPreTrainedModel(PreTrainedModel, nn.Module):
 
 
 class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
-    """Pre-training model (MoCo queues, FAM/VTM/FTM/MLM); filled in by hmmc_amd.pretrain (see __init__)."""
+    """Pre-training model: online + momentum encoders, five negative queues, FAM / VTM / FTM / MLM losses
+    (reference modules/modeling.py:88-436).  forward() keeps the reference's order: online encoders, EMA update,
+    key encoders, losses against the OLD queues, enqueue, MLM."""
+
+    PAD_ID, CLS_ID, MASK_ID, VOCAB = 49407, 49406, 49394, 49408     # ClipTokenizer ids (tokenization_clip.py:75-87)
+
+    def __init__(self, cross_config, task_config):
+        super(BirdPreTrainedModel, self).__init__(cross_config)
+        self.task_config = task_config
+        self.rank = task_config.local_rank
+        self.mlm_probability = cross_config.mlm_probability
+        self.top_frames = task_config.top_frames
+        self.weight_FAM, self.weight_VTM = cross_config.weight_FAM, cross_config.weight_VTM
+        self.weight_FTM, self.weight_MLM = cross_config.weight_FTM, cross_config.weight_MLM
+        self.contrast_momentum = task_config.contrast_momentum
+        self.contrast_temperature = task_config.contrast_temperature
+        self.contrast_num_negative = task_config.contrast_num_negative
+        E = cross_config.temporal_hidden_size
+        self.text_encoder = TextEncoder(self.task_config, cross_config)
+        self.text_encoder_k = TextEncoder(self.task_config, cross_config)
+        self.t_projector = MLP(num_layers=cross_config.proj_num_layers)
+        self.t_projector_k = MLP(num_layers=cross_config.proj_num_layers)
+        self.cls = BertLMPredictionHead(E, self.VOCAB, "gelu")
+        self.visual_encoder = VisualEncoder(self.task_config, cross_config)
+        self.visual_encoder_k = VisualEncoder(self.task_config, cross_config)
+        self.v_projector = MLP(num_layers=cross_config.proj_num_layers)
+        self.v_projector_k = MLP(num_layers=cross_config.proj_num_layers)
+        self.v_predictor = MLP(num_layers=cross_config.pred_num_layers)
+        self.model_pairs = [[self.visual_encoder, self.visual_encoder_k], [self.text_encoder, self.text_encoder_k],
+                            [self.v_projector, self.v_projector_k], [self.t_projector, self.t_projector_k]]
+        self.copy_params()
+        K, Fm = self.contrast_num_negative, self.task_config.max_frames
+        for name, width in (("queue_v_cross_ng", K), ("queue_frame_proj_ng", K * Fm), ("queue_frame_cross_ng", K * Fm),
+                            ("queue_title_cross_ng", K), ("queue_tag_cross_ng", K)):
+            q = torch.randn(E, width)
+            self.register_buffer(name, torch.nn.functional.normalize(q, dim=0))
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        self.loss_fct = CrossEn()
+        self._ema_table = None
+        self._mlm_draws = None          # tests inject the reference's recorded random draws here
+
+    # ---- momentum encoders
+    @torch.no_grad()
+    def copy_params(self):
+        for online, key in self.model_pairs:
+            for param, param_k in zip(online.parameters(), key.parameters()):
+                param_k.data.copy_(param.data)
+                param_k.requires_grad = False
+
+    @torch.no_grad()
+    def _momentum_update(self):
+        """p_k = p_k * m + p * (1 - m) for the 4 model pairs, one multi-tensor launch
+        (reference modules/modeling.py:238-242, 362 tensors in three kernels each)."""
+        from .optimization import _TensorTable, _dtype_flag
+        from ._lib import call, ptr
+        rows = []
+        for online, key in self.model_pairs:
+            for param, param_k in zip(online.parameters(), key.parameters()):
+                rows.append((param_k.data_ptr(), param.data_ptr(), 0, 0, param.numel(), _dtype_flag(param)))
+        dev = next(self.parameters()).device
+        if self._ema_table is None or self._ema_table.device != dev:
+            self._ema_table = _TensorTable(dev)
+        tbl = self._ema_table.build(rows)
+        m = float(self.contrast_momentum)
+        call("hmmc_mt_ema", ptr(tbl.tab), ptr(tbl.chunk), tbl.nchunks, m, 1.0 - m)
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, v_fea_k, tag_fea_k, title_fea_k, frame_fea_k, frame_proj_k):
+        """gather keys from every rank, normalise, overwrite queue columns [ptr, ptr+B) (frame queues: [ptr*F, (ptr+B)*F))
+        (reference modules/modeling.py:244-284)."""
+        b, F, E = frame_fea_k.shape
+        packed = torch.cat([v_fea_k, tag_fea_k, title_fea_k, frame_fea_k.reshape(b, F * E), frame_proj_k.reshape(b, F * E)], dim=1)
+        packed = dist_collect(packed)
+        B = packed.shape[0]
+        v, tag, title = packed[:, :E], packed[:, E:2 * E], packed[:, 2 * E:3 * E]
+        fr = packed[:, 3 * E:3 * E + F * E].reshape(B * F, E)
+        fp = packed[:, 3 * E + F * E:].reshape(B * F, E)
+        ptr_ = int(self.queue_ptr)
+        ops.enqueue(v.contiguous(), self.queue_v_cross_ng, ptr_)
+        ops.enqueue(tag.contiguous(), self.queue_tag_cross_ng, ptr_)
+        ops.enqueue(title.contiguous(), self.queue_title_cross_ng, ptr_)
+        ops.enqueue(fp.contiguous(), self.queue_frame_proj_ng, ptr_ * F)
+        ops.enqueue(fr.contiguous(), self.queue_frame_cross_ng, ptr_ * F)
+        self.queue_ptr[0] = (ptr_ + B) % self.contrast_num_negative
+
+    # ---- MLP with train-mode BatchNorm (batch statistics shared over ranks)
+    def _mlp(self, mlp, x):
+        lin1, bn, lin2 = mlp.linear_hidden[1], mlp.linear_hidden[2], mlp.linear_out
+        out, mean, var, n = Fn.MlpFn.apply(x, lin1.weight, lin1.bias, bn.weight, bn.bias, lin2.weight, lin2.bias, bn.eps)
+        with torch.no_grad():
+            mom = bn.momentum
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var * (n / (n - 1).clamp(min=1.0)), alpha=mom)
+            bn.num_batches_tracked += 1
+        return out
+
+    # ---- losses
+    def contrastive_loss(self, q, k, queue):
+        """reference modules/modeling.py:286-313 (mean over rows)."""
+        q, k = q.reshape(-1, q.shape[-1]), k.reshape(-1, k.shape[-1])
+        return Fn.MocoLossFn.apply(q, k, queue, self.contrast_temperature, 1.0 / q.shape[0])
+
+    def frame_self_loss(self, frame_fea, frame_fea_k, queue_frame_ng):
+        """FAM (reference modules/modeling.py:315-323): all 2(F-1) contrastive_loss calls in one batched launch set."""
+        b, F, E = frame_fea.shape
+        q = torch.cat([frame_fea[:, :-1].reshape(-1, E), frame_fea[:, 1:].reshape(-1, E)])
+        k = torch.cat([frame_fea_k[:, 1:].reshape(-1, E), frame_fea_k[:, :-1].reshape(-1, E)])
+        return Fn.MocoLossFn.apply(q, k, queue_frame_ng, self.contrast_temperature, 1.0 / (b * (F - 1)))
+
+    def frame_cross_loss(self, frame_fea, frame_fea_k, queue_frame_ng, text_fea, text_fea_k, queue_text_ng):
+        """FTM (reference modules/modeling.py:325-332): 2F calls batched into two (one per queue)."""
+        b, F, E = frame_fea.shape
+        w = 1.0 / (b * F)
+        t2f = Fn.MocoLossFn.apply(text_fea.unsqueeze(1).expand(b, F, E).reshape(-1, E), frame_fea_k.reshape(-1, E),
+                                  queue_frame_ng, self.contrast_temperature, w)
+        f2t = Fn.MocoLossFn.apply(frame_fea.reshape(-1, E), text_fea_k.unsqueeze(1).expand(b, F, E).reshape(-1, E),
+                                  queue_text_ng, self.contrast_temperature, w)
+        return t2f + f2t
+
+    def mask(self, input_ids, vocab_size, device, targets=None, masked_indices=None, probability_matrix=None):
+        """BERT masking with the reference's quirks (modules/modeling.py:181-205): never masks EOT (its "pad") or SOT;
+        80% [MASK]=49394, 10% random id; the random draws are made on the CPU like the reference's."""
+        if self._mlm_draws is not None:
+            masked, replaced, randsel, words = [t.to(input_ids.device) for t in self._mlm_draws]
+            masked, replaced, randsel = masked.bool(), replaced.bool(), randsel.bool()
+        else:
+            shape = input_ids.shape
+            masked = torch.bernoulli(probability_matrix).bool().to(input_ids.device)
+            replaced = torch.bernoulli(torch.full(shape, 0.8)).bool().to(input_ids.device)
+            randsel = torch.bernoulli(torch.full(shape, 0.5)).bool().to(input_ids.device)
+            words = torch.randint(vocab_size, shape, dtype=torch.long).to(input_ids.device)
+        masked = masked.clone()
+        masked[input_ids == self.PAD_ID] = False
+        masked[input_ids == self.CLS_ID] = False
+        if targets is not None:
+            targets[~masked] = -100
+        rep = replaced & masked
+        input_ids[rep] = self.MASK_ID
+        rnd = randsel & masked & ~rep
+        input_ids[rnd] = words[rnd]
+        return (input_ids, targets) if targets is not None else input_ids
+
+    def get_mlm_loss(self, input_ids, input_mask):
+        ids = input_ids.clone()
+        labels = ids.clone()
+        prob = torch.full(labels.shape, self.mlm_probability)
+        ids, labels = self.mask(ids, self.VOCAB, input_mask.device, targets=labels, probability_matrix=prob)
+        hidden = self.text_encoder(ids, input_mask, return_hidden=True)
+        return self.calculate_mlm_loss(hidden, labels)
+
+    def calculate_mlm_loss(self, sequence_output_mlm, labels):
+        c = self.cls
+        return Fn.MlmHeadFn.apply(sequence_output_mlm, labels, c.transform.dense.weight, c.transform.dense.bias,
+                                  c.transform.LayerNorm.weight, c.transform.LayerNorm.bias, c.decoder.weight, c.bias)
+
+    def forward(self, video_data, video_frame, tag_ids, tag_mask, title_ids, title_mask, global_step):
+        tag_ids = tag_ids.view(-1, tag_ids.shape[-1])
+        tag_mask = tag_mask.view(-1, tag_mask.shape[-1])
+        title_ids = title_ids.view(-1, title_ids.shape[-1])
+        title_mask = title_mask.view(-1, title_mask.shape[-1])
+        video = torch.as_tensor(video_data)
+        if not self.training:
+            return None
+        bird = self.task_config.dataset == "bird"
+        v_fea, frame_fea = self.visual_encoder(video, video_frame)
+        tag_fea = self.text_encoder(tag_ids, tag_mask) if bird else None
+        title_fea = self.text_encoder(title_ids, title_mask)
+        bs, frame, hidden = frame_fea.shape
+        frame_proj = self._mlp(self.v_projector, frame_fea.reshape(-1, hidden))
+        frame_pred = self._mlp(self.v_predictor, frame_proj).view(bs, frame, hidden)
+        frame_proj = frame_proj.view(bs, frame, hidden)
+        with torch.no_grad():
+            self._momentum_update()
+            tag_fea_k = self.text_encoder_k(tag_ids, tag_mask)
+            title_fea_k = self.text_encoder_k(title_ids, title_mask)
+            v_fea_k, frame_fea_k = self.visual_encoder_k(video, video_frame)
+            frame_proj_k = self._mlp(self.v_projector_k, frame_fea_k.reshape(-1, hidden)).view(bs, frame, hidden)
+        # The losses (and their backward, which runs after the enqueue below) must see the OLD negatives: one
+        # snapshot per queue per step (the reference clones the queue inside each of its 48 contrastive_loss calls).
+        q_proj, q_cross = self.queue_frame_proj_ng.clone(), self.queue_frame_cross_ng.clone()
+        q_title, q_v = self.queue_title_cross_ng.clone(), self.queue_v_cross_ng.clone()
+        q_tag = self.queue_tag_cross_ng.clone() if bird else None
+        loss_FAM = self.frame_self_loss(frame_pred, frame_proj_k, q_proj)
+        v_title = self.contrastive_loss(v_fea, title_fea_k, q_title) + self.contrastive_loss(title_fea, v_fea_k, q_v)
+        if bird:
+            v_tag = self.contrastive_loss(v_fea, tag_fea_k, q_tag) + self.contrastive_loss(tag_fea, v_fea_k, q_v)
+            loss_VTM = (v_tag + v_title) / 2
+        else:
+            loss_VTM = v_title
+        loss_FTM = 0.0
+        if self.task_config.use_frame_fea:
+            ft = self.frame_cross_loss(frame_fea, frame_fea_k, q_cross, title_fea, title_fea_k, q_title)
+            if bird:
+                ftag = self.frame_cross_loss(frame_fea, frame_fea_k, q_cross, tag_fea, tag_fea_k, q_tag)
+                loss_FTM = (ftag + ft) / 2
+            else:
+                loss_FTM = ft
+        self._dequeue_and_enqueue(v_fea_k, tag_fea_k, title_fea_k, frame_fea_k, frame_proj_k)
+        mlm = self.get_mlm_loss(title_ids, title_mask)
+        loss_MLM = (self.get_mlm_loss(tag_ids, tag_mask) + mlm) / 2 if bird else mlm
+        self.last_losses = (loss_FAM, loss_VTM, loss_FTM, loss_MLM)
+        loss = self.weight_FAM * loss_FAM + self.weight_VTM * loss_VTM + self.weight_FTM * loss_FTM + self.weight_MLM * loss_MLM
+        if self.rank == 0 and getattr(self.task_config, "logdir", None):
+            self.task_config.writer.add_scalars("loss", {"loss": float(loss)}, global_step=global_step)
+        return loss
 
     def loose_similarity(self, sequence_output, visual_output):
         """100 * n(q) n(v)^T; visual may be [bv,512] or [bv,F,512] -> [bq,bv,F]

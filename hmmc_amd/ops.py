@@ -339,3 +339,102 @@ def enqueue(keys, queue, col0):
     R, E = keys.shape
     assert queue.shape[0] == E
     call("hmmc_enqueue", ptr(keys), ptr(queue), R, E, queue.shape[1], int(col0))
+
+
+# ----------------------------------------------------------------------------- pre-training (MoCo) heads
+
+def bn_stats(h):
+    """-> sums [2, N]: column sum and sum of squares of this rank's rows."""
+    M, N = h.shape
+    sums = torch.empty((2, N), dtype=torch.float32, device=h.device)
+    wsb = query("hmmc_bn_workspace", M, N)
+    ws = workspace(wsb, h.device, "bn")
+    call("hmmc_bn_stats", ptr(h), ptr(sums), M, N, ptr(ws), wsb)
+    return sums
+
+
+def bn_apply_relu(h, mean, rstd, gamma, beta):
+    M, N = h.shape
+    y = torch.empty_like(h)
+    call("hmmc_bn_apply_relu", ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y), M, N)
+    return y
+
+
+def bn_bwd_reduce(dy, y, h, mean, rstd):
+    M, N = h.shape
+    sums = torch.empty((2, N), dtype=torch.float32, device=h.device)
+    wsb = query("hmmc_bn_workspace", M, N)
+    ws = workspace(wsb, h.device, "bn")
+    call("hmmc_bn_bwd_reduce", ptr(dy), ptr(y), ptr(h), ptr(mean), ptr(rstd), ptr(sums), M, N, ptr(ws), wsb)
+    return sums
+
+
+def bn_bwd_apply(dy, y, h, mean, rstd, gamma, sums, n_global):
+    M, N = h.shape
+    dh = torch.empty_like(h)
+    call("hmmc_bn_bwd_apply", ptr(dy), ptr(y), ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(sums), ptr(dh), M, N,
+         1.0 / float(n_global))
+    return dh
+
+
+def rowdot(a, b):
+    rows, D = a.shape
+    out = torch.empty(rows, dtype=torch.float32, device=a.device)
+    call("hmmc_rowdot", ptr(a), ptr(b), ptr(out), rows, D)
+    return out
+
+
+def moco_loss_fwd(S, lpos, temperature, w):
+    R, Kq = S.shape
+    lse = torch.empty(R, dtype=torch.float32, device=S.device)
+    rowloss = torch.empty(R, dtype=torch.float32, device=S.device)
+    loss = torch.empty((), dtype=torch.float32, device=S.device)
+    call("hmmc_moco_loss_fwd", ptr(S), ptr(lpos), ptr(lse), ptr(rowloss), ptr(loss), R, Kq, float(temperature), float(w))
+    return loss, lse
+
+
+def moco_loss_bwd_(S, lpos, lse, gout, temperature, w):
+    """Overwrites S with dS; returns dlpos."""
+    R, Kq = S.shape
+    gout = gout.contiguous().float()
+    dlpos = torch.empty(R, dtype=torch.float32, device=S.device)
+    call("hmmc_moco_loss_bwd", ptr(S), ptr(lpos), ptr(lse), ptr(gout), ptr(dlpos), R, Kq, float(temperature), float(w))
+    return dlpos
+
+
+def row_axpy_(y, s, x):
+    rows, D = y.shape
+    call("hmmc_row_axpy", ptr(y), ptr(s), ptr(x), rows, D)
+    return y
+
+
+def gelu_erf_fwd(x):
+    y = torch.empty_like(x)
+    call("hmmc_gelu_erf_fwd", ptr(x), ptr(y), x.numel())
+    return y
+
+
+def gelu_erf_bwd(x, dy):
+    dx = torch.empty_like(x)
+    call("hmmc_gelu_erf_bwd", ptr(x), ptr(dy), ptr(dx), x.numel())
+    return dx
+
+
+def ce_fwd(logits, labels):
+    """-> (loss_sum, lse, count) with ignore_index < 0."""
+    _chk(logits, torch.float32, "logits")
+    _chk(labels, torch.int64, "labels")
+    R, V = logits.shape
+    lse = torch.empty(R, dtype=torch.float32, device=logits.device)
+    rowloss = torch.empty(R, dtype=torch.float32, device=logits.device)
+    count = torch.empty(1, dtype=torch.float32, device=logits.device)
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    call("hmmc_ce_fwd", ptr(logits), ptr(labels), ptr(lse), ptr(rowloss), ptr(count), ptr(loss), R, V)
+    return loss, lse, count
+
+
+def ce_bwd_(logits, labels, lse, gout, count):
+    R, V = logits.shape
+    gout = gout.contiguous().float()
+    call("hmmc_ce_bwd", ptr(logits), ptr(labels), ptr(lse), ptr(gout), ptr(count), R, V)
+    return logits

@@ -146,6 +146,41 @@ int hmmc_mt_ema(const long* tab, const int* chunk, int nchunks, float momentum, 
 /* _dequeue_and_enqueue (modules/modeling.py:262-278): queue[:, col0:col0+R] = normalize(keys).T; queue is [E][W]. */
 int hmmc_enqueue(const float* keys, float* queue, int R, int E, long W, long col0, hmmc_stream_t stream);
 
+/* BatchNorm1d (train mode) of the MoCo projector / predictor MLPs (modules/modeling.py:788-807, SyncBN via :115-129).
+ * hmmc_bn_stats: sums[0][n] = sum_m h, sums[1][n] = sum_m h^2 over THIS rank's rows (the caller all-reduces over ranks);
+ * hmmc_bn_apply_relu: y = relu((h - mean) * rstd * gamma + beta);
+ * hmmc_bn_bwd_reduce: sums[0] = sum d, sums[1] = sum d * xhat with d = dy * (y > 0);
+ * hmmc_bn_bwd_apply: dh = gamma * rstd * (d - sums[0]*inv_n - xhat * sums[1]*inv_n), inv_n = 1 / global row count. */
+size_t hmmc_bn_workspace(int M, int N);
+int hmmc_bn_stats(const float* h, float* sums, int M, int N, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+int hmmc_bn_apply_relu(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                       long M, int N, hmmc_stream_t stream);
+int hmmc_bn_bwd_reduce(const float* dy, const float* y, const float* h, const float* mean, const float* rstd, float* sums,
+                       int M, int N, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+int hmmc_bn_bwd_apply(const float* dy, const float* y, const float* h, const float* mean, const float* rstd,
+                      const float* gamma, const float* sums, float* dh, long M, int N, float inv_n, hmmc_stream_t stream);
+
+/* contrastive_loss against a negative queue (modules/modeling.py:286-313), for R stacked (q, k) rows sharing one queue:
+ * lpos[r] = <qn[r], kn[r]> (hmmc_rowdot), S = qn . queue [R, Kq] (hmmc_gemm_f32),
+ * loss = sum_r w * (logsumexp([lpos[r], S[r][:]] / T) - lpos[r] / T).  The backward overwrites S with dS. */
+int hmmc_rowdot(const float* a, const float* b, float* out, int rows, int D, hmmc_stream_t stream);
+int hmmc_moco_loss_fwd(const float* S, const float* lpos, float* lse, float* rowloss, float* loss, int R, long Kq,
+                       float temperature, float w, hmmc_stream_t stream);
+int hmmc_moco_loss_bwd(float* S, const float* lpos, const float* lse, const float* grad_out, float* dlpos, int R, long Kq,
+                       float temperature, float w, hmmc_stream_t stream);
+/* y[r][:] += s[r] * x[r][:] */
+int hmmc_row_axpy(float* y, const float* s, const float* x, long rows, int D, hmmc_stream_t stream);
+
+/* MLM head pieces: erf-GELU (modules/module_cross.py:33-39) and F.cross_entropy(ignore_index < 0)
+ * (modules/modeling.py:171-179): loss = SUM over valid rows of (lse - logit[label]), count[0] = #valid rows;
+ * the backward overwrites logits with (softmax - onehot) * grad_out / count on valid rows, 0 elsewhere. */
+int hmmc_gelu_erf_fwd(const float* x, float* y, long n, hmmc_stream_t stream);
+int hmmc_gelu_erf_bwd(const float* x, const float* dy, float* dx, long n, hmmc_stream_t stream);
+int hmmc_ce_fwd(const float* logits, const long* labels, float* lse, float* rowloss, float* count, float* loss, int R, long V,
+                hmmc_stream_t stream);
+int hmmc_ce_bwd(float* logits, const long* labels, const float* lse, const float* grad_out, const float* count, int R, long V,
+                hmmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

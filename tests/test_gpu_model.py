@@ -231,7 +231,7 @@ def test_bertadam_vs_reference_golden():
                     nbad = int((mine.float().cpu() != ref).sum())
                     assert nbad == 0, f"{name}.{nm}{step}: {nbad} fp16 elements differ from the reference"
                 else:
-                    close(mine, ref, 1e-9, 2e-6, f"{name}.{nm}{step}")
+                    close(mine, ref, 2e-8, 2e-6, f"{name}.{nm}{step}")
 
 
 def prep_optimizer(model, cfg, t_total):

@@ -1,0 +1,168 @@
+"""GPU parity tests of the pre-training path (BirdPreTrainedModel: MoCo queues, EMA, FAM/VTM/FTM/MLM) against the
+reference's golden vectors (tests/golden/moco_*.npz, 5 steps with queue wrap-around) and the CPU oracle."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import golden  # noqa: E402
+from hmmc_amd import ops, synth  # noqa: E402
+from hmmc_amd import functional as Fn  # noqa: E402
+from oracle import hmmc_oracle as O  # noqa: E402
+from test_gpu_model import close, prep_optimizer, task_config  # noqa: E402
+
+DEV = "cuda"
+
+
+def test_mlp_fn_vs_torch_batchnorm():
+    torch.manual_seed(0)
+    x = torch.randn(48, 512)
+    lin1, bn, lin2 = torch.nn.Linear(512, 4096), torch.nn.BatchNorm1d(4096), torch.nn.Linear(4096, 512)
+    with torch.no_grad():
+        bn.weight.normal_(1, 0.1)
+        bn.bias.normal_(0, 0.1)
+    ref_in = x.clone().requires_grad_()
+    ref = lin2(torch.relu(bn(lin1(ref_in))))
+    w = torch.randn(48, 512)
+    (ref * w).sum().backward()
+    P = [p.detach().clone().to(DEV).requires_grad_() for p in (lin1.weight, lin1.bias, bn.weight, bn.bias, lin2.weight, lin2.bias)]
+    xg = x.to(DEV).requires_grad_()
+    out, mean, var, n = Fn.MlpFn.apply(xg, *P, bn.eps)
+    (out * w.to(DEV)).sum().backward()
+    close(out, ref, 2e-4, 1e-4, "mlp out")
+    close(xg.grad, ref_in.grad, 2e-4, 2e-3, "dx")
+    for mine, refp, nm in zip(P, (lin1.weight, lin1.bias, bn.weight, bn.bias, lin2.weight, lin2.bias),
+                              ("w1", "b1", "gamma", "beta", "w2", "b2")):
+        close(mine.grad, refp.grad, 3e-4, 2e-3, nm)
+    close(mean * 0.1, bn.running_mean, 1e-5, 1e-4, "running mean")
+
+
+@pytest.mark.parametrize("R,Kq", [(4, 16), (24, 64), (16, 64), (40, 192), (352, 12288)])
+def test_moco_loss_fn_vs_oracle(R, Kq):
+    E = 512
+    q, k = synth.normal("moco.q", (R, E)), synth.normal("moco.k", (R, E))
+    queue = torch.nn.functional.normalize(synth.normal("moco.queue", (E, Kq)), dim=0)
+    qo = q.clone().requires_grad_()
+    ref = O.contrastive_loss(qo, k, queue, 0.07)
+    ref.backward()
+    qg = q.to(DEV).requires_grad_()
+    loss = Fn.MocoLossFn.apply(qg, k.to(DEV), queue.to(DEV), 0.07, 1.0 / R)
+    loss.backward()
+    close(loss, ref, 1e-5, 1e-5, "loss")
+    close(qg.grad, qo.grad, 1e-6, 1e-3, "dq")
+
+
+def test_mlm_head_fn_vs_oracle():
+    sd = synth.pretrain_state(synth.TINY, 16, 4)
+    hidden = synth.normal("mlm.hidden", (3, 20, 512), 0.5)
+    labels = torch.full((3, 20), -100, dtype=torch.long)
+    labels[0, 3], labels[1, 7], labels[2, 19], labels[2, 1] = 17, 40000, 49407, 5
+    ho = hidden.clone().requires_grad_()
+    sdo = {k: sd[k].clone().requires_grad_() for k in sd if k.startswith("cls.")}
+    scores = O.mlm_head(ho, sdo)
+    ref = torch.nn.functional.cross_entropy(scores.view(-1, scores.shape[-1]), labels.view(-1), ignore_index=-100)
+    ref.backward()
+    hg = hidden.to(DEV).requires_grad_()
+    P = {k: sd[k].clone().to(DEV).requires_grad_() for k in sdo}
+    loss = Fn.MlmHeadFn.apply(hg, labels.to(DEV), P["cls.transform.dense.weight"], P["cls.transform.dense.bias"],
+                              P["cls.transform.LayerNorm.weight"], P["cls.transform.LayerNorm.bias"],
+                              P["cls.decoder.weight"], P["cls.bias"])
+    loss.backward()
+    close(loss, ref, 1e-5, 1e-5, "mlm loss")
+    close(hg.grad, ho.grad, 1e-6, 2e-3, "dhidden")
+    close(P["cls.decoder.weight"].grad, sdo["cls.decoder.weight"].grad, 1e-6, 2e-3, "ddecoder")
+    close(P["cls.bias"].grad, sdo["cls.bias"].grad, 1e-6, 2e-3, "dbias")
+    close(P["cls.transform.dense.weight"].grad, sdo["cls.transform.dense.weight"].grad, 1e-6, 2e-3, "ddense")
+
+
+def test_pretrain_steps_vs_reference_golden():
+    """5 steps of main_pretrain.py's loop; K=16, B=4 wraps the queue pointer at step 4."""
+    from hmmc_amd.modeling import BirdPreTrainedModel
+    from hmmc_amd.optimization import clip_grad_norm_
+    g = golden("moco_aswritten")
+    K, B, Fr = int(g["K"]), int(g["B"]), int(g["F"])
+    sd = synth.pretrain_state(synth.TINY, K, Fr)
+    cfg = task_config(contrast_num_negative=K, max_frames=Fr, dataset="chvtt", lr=2e-3, text_lr=1e-3, coef_lr=0.5,
+                      weight_decay=0.05)
+    model = BirdPreTrainedModel.from_pretrained("cross-base", state_dict=sd, task_config=cfg).to(DEV).train()
+    opt = prep_optimizer(model, cfg, 10)
+    for step in range(5):
+        vid, vf, tg, gm, ti, tm = [t.to(DEV) for t in synth.pretrain_batch(B, Fr, tag=f"moco.s{step}")]
+        model._mlm_draws = [torch.from_numpy(g[f"mlm_{n}{step}"]) for n in ("masked", "replaced", "randsel", "words")]
+        loss = model(vid, vf, tg, gm, ti, tm, step + 1)
+        loss.backward()
+        tn = clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        fam, vtm, ftm, mlm = [float(x) for x in model.last_losses]
+        tol = 5e-2 if step < 2 else 0.4          # weights move (chaotically in fp16, see test_gpu_model) from step 2 on
+        close(fam, g[f"fam{step}"], tol, what=f"fam{step}")
+        close(ftm, g[f"ftm{step}"], tol, what=f"ftm{step}")
+        close(mlm, g[f"mlm{step}"], tol, what=f"mlm{step}")
+        close(loss, g[f"loss{step}"], tol, what=f"loss{step}")
+        assert int(model.queue_ptr) == int(g[f"ptr{step}"][0]), "queue pointer"
+        S = model.state_dict()
+        if step == 0:
+            close(tn, g["gnorm0"], 0, 0.15, "gnorm0")
+            # EMA of fp16 / fp32 key-encoder weights after the first update: bit patterns
+            for k in ("visual_encoder_k.visual.conv1.weight", "text_encoder_k.text_projection",
+                      "visual_encoder_k.temporal_transformer.resblocks.0.mlp.c_fc.weight",
+                      "v_projector_k.linear_out.weight", "text_encoder_k.ln_final.weight"):
+                mine = S[k].reshape(-1)[:16].float().cpu()
+                ref = torch.from_numpy(g[f"s0:{k}"])
+                assert torch.equal(mine, ref), f"EMA {k}: {mine} vs {ref}"
+            for k in ("v_projector.linear_hidden.2.running_mean", "v_projector.linear_hidden.2.running_var",
+                      "v_projector_k.linear_hidden.2.running_mean", "v_predictor.linear_hidden.2.running_var"):
+                close(S[k].reshape(-1)[:16], g[f"s0:{k}"], 2e-3, 2e-2, k)
+            for qn in ("queue_v_cross_ng", "queue_title_cross_ng", "queue_tag_cross_ng", "queue_frame_proj_ng",
+                       "queue_frame_cross_ng"):
+                close(S[qn][:32], g[f"q0:{qn}"], 2e-3, what=qn)
+        if step == 4:
+            # after the wrap-around every column has been overwritten once more: untouched columns must be intact
+            for qn in ("queue_v_cross_ng", "queue_frame_cross_ng"):
+                q = S[qn][:32].float().cpu().numpy()
+                assert np.isfinite(q).all()
+                close(np.linalg.norm(S[qn].float().cpu().numpy(), axis=0), 1.0, 1e-4, what=f"{qn} column norms")
+
+
+def test_pretrain_gradients_vs_oracle():
+    """Every parameter gradient of step 0 against the fp32 oracle: direction (cosine) and norm."""
+    from hmmc_amd.modeling import BirdPreTrainedModel
+    g = golden("moco_fp32")
+    K, B, Fr = int(g["K"]), int(g["B"]), int(g["F"])
+    raw = synth.pretrain_state(synth.TINY, K, Fr)
+    cfg = task_config(contrast_num_negative=K, max_frames=Fr, dataset="chvtt")
+    model = BirdPreTrainedModel.from_pretrained("cross-base", state_dict=raw, task_config=cfg).to(DEV).train()
+    batch = synth.pretrain_batch(B, Fr, tag="moco.s0")
+    draws = [torch.from_numpy(g[f"mlm_{n}0"]) for n in ("masked", "replaced", "randsel", "words")]
+    model._mlm_draws = draws
+    loss = model(*[t.to(DEV) for t in batch], 1)
+    loss.backward()
+    sd = {}
+    for k, v in raw.items():
+        trainable = v.is_floating_point() and not any(s in k for s in ("_k.", "queue_", "running_", "num_batches"))
+        sd[k] = v.clone().requires_grad_(trainable)
+    sd["cls.decoder.bias"] = sd["cls.bias"]
+    queues = {k: sd[k] for k in sd if k.startswith("queue_") and k != "queue_ptr"}
+    d2 = [d.bool() if i < 3 else d for i, d in enumerate(draws)]
+    ref, parts, _ = O.pretrain_loss(batch, sd, queues, 0, K, mode="fp32", mlm_draws=d2)
+    ref.backward()
+    close(loss, ref, 5e-2, what="loss")
+    bad = []
+    for n, p in model.named_parameters():
+        if not p.requires_grad or "t_projector" in n:
+            continue
+        key = "cls.bias" if n == "cls.decoder.bias" else n
+        assert p.grad is not None, n
+        a, b = p.grad.float().cpu().flatten(), sd[key].grad.flatten()
+        if float(b.norm()) < 1e-6:        # biases in front of BatchNorm: the true gradient is zero, both sides hold noise
+            assert float(a.norm()) < 1e-4, n
+            continue
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-20))
+        ratio = float(a.norm() / (b.norm() + 1e-20))
+        if cos < 0.97 or abs(ratio - 1) > 0.1:
+            bad.append((n, round(cos, 4), round(ratio, 3), float(b.norm())))
+    assert not bad, f"{len(bad)} gradients disagree with the oracle: {bad[:12]}"

@@ -168,3 +168,58 @@ def test_train_steps_fp32():
             for key in g.files:
                 if key.startswith(f"p{step}:"):
                     close(sd[key.split(":", 1)[1]].detach().reshape(-1)[:16], g[key], 2e-4, 1e-3, key)
+
+
+def _moco_oracle_run(mode, nsteps=5):
+    """Reference main_pretrain.py loop on the oracle: forward (EMA, queues, MLM), backward, clip, BertAdam."""
+    g = golden(f"moco_{mode}")
+    K, B, Fr = int(g["K"]), int(g["B"]), int(g["F"])
+    raw = synth.pretrain_state(synth.TINY, K, Fr)
+    sd = {}
+    for k, v in raw.items():
+        trainable = v.is_floating_point() and not any(s in k for s in ("_k.", "queue_", "running_", "num_batches"))
+        sd[k] = v.clone().requires_grad_(trainable)
+    sd["cls.decoder.bias"] = sd["cls.bias"]
+    queues = {k: sd[k] for k in sd if k.startswith("queue_") and k != "queue_ptr"}
+    names = [k for k, v in sd.items() if v.requires_grad and k != "cls.decoder.bias"]
+    hp = _groups(names, 2e-3, 1e-3, 0.5, 0.05)
+    state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in names}
+    ptr = 0
+    out = []
+    for step in range(nsteps):
+        batch = synth.pretrain_batch(B, Fr, tag=f"moco.s{step}")
+        draws = [t(g[f"mlm_{n}{step}"]) for n in ("masked", "replaced", "randsel", "words")]
+        draws = [d.bool() if i < 3 else d for i, d in enumerate(draws)]
+        for k in names:
+            sd[k].grad = None
+        loss, parts, ptr = O.pretrain_loss(batch, sd, queues, ptr, K, mode=mode, mlm_draws=draws)
+        loss.backward()
+        used = [sd[k] for k in names if sd[k].grad is not None]
+        tn = torch.nn.utils.clip_grad_norm_(used, 1.0)
+        with torch.no_grad():
+            for k in names:
+                if sd[k].grad is None:
+                    continue
+                m, v = state[k]
+                p, m, v, _ = O.bert_adam_step(sd[k].data, sd[k].grad, m, v, step, hp[k][0], 10, 0.1, hp[k][1])
+                sd[k].data.copy_(p)
+                state[k] = (m, v)
+        out.append((loss.detach(), parts, tn, ptr))
+        yield step, g, sd, queues, loss.detach(), parts, tn, ptr
+
+
+def test_pretrain_steps_fp32():
+    for step, g, sd, queues, loss, parts, tn, ptr in _moco_oracle_run("fp32"):
+        fam, vtm, ftm, mlm = [float(x) for x in parts]
+        close(fam, g[f"fam{step}"], 2e-3, what=f"fam{step}")
+        close(ftm, g[f"ftm{step}"], 2e-3, what=f"ftm{step}")
+        close(mlm, g[f"mlm{step}"], 2e-3, what=f"mlm{step}")
+        close(loss, g[f"loss{step}"], 2e-3, what=f"loss{step}")
+        assert ptr == int(g[f"ptr{step}"][0])
+        if step == 0:
+            close(tn, g["gnorm0"], 0, 5e-3, "gnorm0")
+            for key in g.files:
+                if key.startswith("s0:"):
+                    close(sd[key[3:]].detach().reshape(-1)[:16], g[key], 1e-5, 1e-4, key)
+                if key.startswith("q0:"):
+                    close(queues[key[3:]][:32], g[key], 1e-5, what=key)
