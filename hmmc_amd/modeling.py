@@ -32,7 +32,10 @@ class _AllGatherCat(torch.autograd.Function):
         x = x.contiguous()
         world = dist.get_world_size()
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x)
+        try:
+            dist.all_gather_into_tensor(out, x)
+        except (RuntimeError, NotImplementedError):      # backends without the flat form (gloo + device tensors)
+            dist.all_gather(list(out.chunk(world, dim=0)), x)
         ctx.rows = x.shape[0]
         return out
 
