@@ -13,66 +13,10 @@
 // reduction over keys is then in-register plus two 16-lane shuffles, and the accumulator tile is
 // directly the B operand of O^T = V^T P^T (k-order permuted identically on the V^T side, which is
 // fetched with ds_read_b64_tr_b16 from the row-major V tile).  Outputs are written 8 bytes per lane.
-#include "common.h"
+#include "attn_common.h"
 
 namespace {
 
-constexpr int DH = 64;          // head dim of every CLIP tower
-constexpr int LDS_STRIDE = 72;  // halves per LDS row (64 + 8 pad): 144 B, keeps 16-B alignment
-
-typedef __attribute__((address_space(3))) fp16x4* lds_tr_ptr;
-
-__device__ __forceinline__ h4 tr_read(const half_t* p) {
-  fp16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)LDS_PTR(p));
-  h4 r;
-  r[0] = (half_t)t[0]; r[1] = (half_t)t[1]; r[2] = (half_t)t[2]; r[3] = (half_t)t[3];
-  return r;
-}
-__device__ __forceinline__ h8 cat4(h4 a, h4 b) {
-  h8 r;
-  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
-  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-  return r;
-}
-
-// copy a [L][64] head slice (row stride ld halves) into an LDS tile [LP][LDS_STRIDE], zero rows >= L
-template <int LP>
-__device__ __forceinline__ void load_tile(half_t* tile, const half_t* src, int L, long ld, int lane) {
-#pragma unroll
-  for (int ps = 0; ps < LP / 8; ++ps) {
-    int row = ps * 8 + (lane >> 3), ch = lane & 7;
-    h8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
-    if (row < L) v = *reinterpret_cast<const h8*>(src + (long)row * ld + ch * 8);
-    *reinterpret_cast<h8*>(tile + row * LDS_STRIDE + ch * 8) = v;
-  }
-}
-
-// fragment of a row-major [rows][64] global slice: 8 halves X[row0 + (lane&15)][ks*32 + 8*(lane>>4) + j]
-__device__ __forceinline__ h8 gfrag(const half_t* src, int row0, int ks, int L, long ld, int lane) {
-  int row = row0 + (lane & 15);
-  h8 v;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
-  if (row < L) v = *reinterpret_cast<const h8*>(src + (long)row * ld + ks * 32 + 8 * (lane >> 4));
-  return v;
-}
-
-// transposed fragment from an LDS tile [r][c] (stride LDS_STRIDE): 8 halves T[kperm][c0 + (lane&15)]
-// with rows r = rA + 4*(lane>>4) + j (j<4) and rB + 4*(lane>>4) + (j-4) (j>=4)
-__device__ __forceinline__ h8 tr_frag(const half_t* tile, int rA, int rB, int c0, int lane) {
-  int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
-  h4 lo = tr_read(tile + (rA + 4 * g + qq) * LDS_STRIDE + c0 + 4 * pp);
-  h4 hi = tr_read(tile + (rB + 4 * g + qq) * LDS_STRIDE + c0 + 4 * pp);
-  return cat4(lo, hi);
-}
-
-struct AttnArgs {
-  const half_t* qkv; half_t* out; float* lse;
-  const half_t* dout; half_t* dqkv;
-  int nseq, L, H, causal;
-};
 
 template <int KT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
@@ -293,10 +237,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 
 }  // namespace
 
+int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream);
+int hmmc_attention_long_bwd(const AttnArgs& p, hipStream_t stream);
+
 extern "C" int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, int nseq, int L, int H, int causal,
                                       hipStream_t stream) {
-  if (!qkv || !out || nseq <= 0 || L <= 0 || H <= 0) return HMMC_ERR_ARG;
-  if (L > 64) return HMMC_ERR_UNSUPPORTED;
+  if (!qkv || !out || !lse || nseq <= 0 || L <= 0 || H <= 0) return HMMC_ERR_ARG;
+  if (L > 256) return HMMC_ERR_UNSUPPORTED;
+  if (L > 64) {
+    AttnArgs pl{};
+    pl.qkv = (const half_t*)qkv; pl.out = (half_t*)out; pl.lse = lse; pl.nseq = nseq; pl.L = L; pl.H = H; pl.causal = causal;
+    return hmmc_attention_long_fwd(pl, stream);
+  }
   AttnArgs p{};
   p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = lse; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   long pairs = (long)nseq * H;
@@ -311,7 +263,13 @@ extern "C" int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, in
 extern "C" int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
                                       int nseq, int L, int H, int causal, hipStream_t stream) {
   if (!qkv || !out || !lse || !dout || !dqkv || nseq <= 0 || L <= 0 || H <= 0) return HMMC_ERR_ARG;
-  if (L > 64) return HMMC_ERR_UNSUPPORTED;
+  if (L > 256) return HMMC_ERR_UNSUPPORTED;
+  if (L > 64) {
+    AttnArgs pl{};
+    pl.qkv = (const half_t*)qkv; pl.out = (half_t*)out; pl.lse = (float*)lse; pl.dout = (const half_t*)dout;
+    pl.dqkv = (half_t*)dqkv; pl.nseq = nseq; pl.L = L; pl.H = H; pl.causal = causal;
+    return hmmc_attention_long_bwd(pl, stream);
+  }
   AttnArgs p{};
   p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = (float*)lse; p.dout = (const half_t*)dout;
   p.dqkv = (half_t*)dqkv; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;

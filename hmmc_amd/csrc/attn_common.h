@@ -1,0 +1,67 @@
+// Shared device helpers of the fused attention kernels (attention_f16.hip, attention_long_f16.hip).
+#pragma once
+#include "common.h"
+
+// plain struct at global scope: shared by the two translation units and their host launchers
+struct HmmcAttnArgs {
+  const half_t* qkv; half_t* out; float* lse;
+  const half_t* dout; half_t* dqkv;
+  int nseq, L, H, causal;
+};
+typedef HmmcAttnArgs AttnArgs;
+
+namespace {
+
+constexpr int DH = 64;          // head dim of every CLIP tower
+constexpr int LDS_STRIDE = 72;  // halves per LDS row (64 + 8 pad): 144 B, keeps 16-B alignment
+
+typedef __attribute__((address_space(3))) fp16x4* lds_tr_ptr;
+
+__device__ __forceinline__ h4 tr_read(const half_t* p) {
+  fp16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)LDS_PTR(p));
+  h4 r;
+  r[0] = (half_t)t[0]; r[1] = (half_t)t[1]; r[2] = (half_t)t[2]; r[3] = (half_t)t[3];
+  return r;
+}
+__device__ __forceinline__ h8 cat4(h4 a, h4 b) {
+  h8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+
+// copy a [L][64] head slice (row stride ld halves) into an LDS tile [LP][LDS_STRIDE], zero rows >= L
+template <int LP>
+__device__ __forceinline__ void load_tile(half_t* tile, const half_t* src, int L, long ld, int lane) {
+#pragma unroll
+  for (int ps = 0; ps < LP / 8; ++ps) {
+    int row = ps * 8 + (lane >> 3), ch = lane & 7;
+    h8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+    if (row < L) v = *reinterpret_cast<const h8*>(src + (long)row * ld + ch * 8);
+    *reinterpret_cast<h8*>(tile + row * LDS_STRIDE + ch * 8) = v;
+  }
+}
+
+// fragment of a row-major [rows][64] global slice: 8 halves X[row0 + (lane&15)][ks*32 + 8*(lane>>4) + j]
+__device__ __forceinline__ h8 gfrag(const half_t* src, int row0, int ks, int L, long ld, int lane) {
+  int row = row0 + (lane & 15);
+  h8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+  if (row < L) v = *reinterpret_cast<const h8*>(src + (long)row * ld + ks * 32 + 8 * (lane >> 4));
+  return v;
+}
+
+// transposed fragment from an LDS tile [r][c] (stride LDS_STRIDE): 8 halves T[kperm][c0 + (lane&15)]
+// with rows r = rA + 4*(lane>>4) + j (j<4) and rB + 4*(lane>>4) + (j-4) (j>=4)
+__device__ __forceinline__ h8 tr_frag(const half_t* tile, int rA, int rB, int c0, int lane) {
+  int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+  h4 lo = tr_read(tile + (rA + 4 * g + qq) * LDS_STRIDE + c0 + 4 * pp);
+  h4 hi = tr_read(tile + (rB + 4 * g + qq) * LDS_STRIDE + c0 + 4 * pp);
+  return cat4(lo, hi);
+}
+
+
+}  // namespace

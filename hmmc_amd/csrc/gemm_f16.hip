@@ -93,24 +93,96 @@ __device__ __forceinline__ h8 read_frag(const char* lds_tile, int row0, int ks, 
   }
 }
 
-// ---- epilogue: lane owns C[m][n..n+3], m = (lane & 15), n = 4 * (lane >> 4) within each 16x16 tile
-template <int MT, int NT>
-__device__ __forceinline__ void epilogue(const GemmArgs& p, f4 (&acc)[MT][NT], int mrow, int ncol, int split) {
-  if (p.splitk > 1) {
-    float* ws = p.ws + (size_t)split * p.M * p.N;
+// ---- epilogue -------------------------------------------------------------------------------------
+// MFMA layout: lane (c = lane & 15, g = lane >> 4) owns C[m0 + c][16j + 4g .. +3] of every 16x16 tile j.
+// Written straight from that layout a store instruction touches 16 rows x 32 B (16 partial lines) and the
+// tile's 128 KiB leave the CU at the store-ISSUE rate.  Instead each wave restages its 16 x 64 half-precision
+// strip through a private 2.3 KiB LDS scratch (144-byte rows: conflict-free b64 writes, aligned b128 reads) so
+// that every global access is 16 B per lane and covers 8 rows x 128 contiguous bytes (whole lines), for the
+// output and equally for the residual / pre-activation operand it reads.  No workgroup barrier: the scratch is
+// wave-private and LDS operations of one wave execute in order.
+constexpr int EPI_ROW = 144;                   // bytes per scratch row
+constexpr int EPI_SCRATCH = 16 * EPI_ROW;      // per wave
+
+template <int MT>
+__device__ __forceinline__ void epilogue_f16(const GemmArgs& p, f4 (&acc)[MT][4], char* scr, int m_base, int n0, int lane) {
+  const int flags = p.flags;
+  const int c = lane & 15, g = lane >> 4;
+  const int io_row = lane >> 3, io_chunk = lane & 7;
+  const int n_io = n0 + io_chunk * 8;
+  const bool n_ok = n_io < p.N;                                   // N % 8 == 0: a 16-byte piece is all-in or all-out
+  h4 bias[4];
+  if (flags & EPI_BIAS) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      int m = mrow + i * 16;
-      if (m >= p.M) continue;
+    for (int j = 0; j < 4; ++j) {
+      int n = n0 + 16 * j + 4 * g;
+      bias[j] = n < p.N ? *reinterpret_cast<const h4*>(p.bias + n) : h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    }
+  }
+  const half_t* src = (flags & EPI_DGELU) ? p.aux_in : ((flags & EPI_RESID) ? p.resid : nullptr);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        int n = ncol + j * 16;
-        if (n < p.N) *reinterpret_cast<f4*>(ws + (size_t)m * p.N + n) = acc[i][j];
+  for (int i = 0; i < MT; ++i) {
+    const int m0 = m_base + i * 16;
+    h4 in[4];
+    if (src) {                                   // coalesced read of the 16 x 64 operand strip
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        int r = io_row + 8 * t, m = m0 + r;
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
+        if (m < p.M && n_ok) v = *reinterpret_cast<const h8*>(src + (size_t)m * p.ldc + n_io);
+        *reinterpret_cast<h8*>(scr + r * EPI_ROW + io_chunk * 16) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) in[j] = *reinterpret_cast<const h4*>(scr + c * EPI_ROW + (16 * j + 4 * g) * 2);
+      __builtin_amdgcn_wave_barrier();
+    }
+    h4 out[4], pre[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f4 v = acc[i][j];
+      if (flags & EPI_BIAS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)bias[j][r];
+      }
+      if (flags & EPI_QGELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pre[j][r] = (half_t)v[r]; out[j][r] = (half_t)qgelu_f16((float)pre[j][r]); }
+      } else if (flags & EPI_DGELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[j][r] = (half_t)(v[r] * qgelu_grad((float)in[j][r]));
+      } else if (flags & EPI_RESID) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[j][r] = (half_t)((float)in[j][r] + r16(v[r]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[j][r] = (half_t)v[r];
       }
     }
-    return;
+    const int npass = ((flags & EPI_QGELU) && p.aux_out) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {   // pass 1 writes the pre-activation to aux_out
+      half_t* dst = pass == 0 ? p.C : p.aux_out;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<h4*>(scr + c * EPI_ROW + (16 * j + 4 * g) * 2) = pass == 0 ? out[j] : pre[j];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        int r = io_row + 8 * t, m = m0 + r;
+        h8 v = *reinterpret_cast<const h8*>(scr + r * EPI_ROW + io_chunk * 16);
+        if (m < p.M && n_ok) *reinterpret_cast<h8*>(dst + (size_t)m * p.ldc + n_io) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
-  const int flags = p.flags;
+}
+
+// split-K partial sums: fp32 slab [split][M][N], 16-byte stores straight from the MFMA layout
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_slab(const GemmArgs& p, f4 (&acc)[MT][NT], int mrow, int ncol, int split) {
+  float* ws = p.ws + (size_t)split * p.M * p.N;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     int m = mrow + i * 16;
@@ -118,33 +190,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f4 (&acc)[MT][NT], i
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       int n = ncol + j * 16;
-      if (n >= p.N) continue;
-      f4 v = acc[i][j];
-      if (flags & EPI_BIAS) {
-        h4 b = *reinterpret_cast<const h4*>(p.bias + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-      }
-      size_t off = (size_t)m * p.ldc + n;
-      h4 o;
-      if (flags & EPI_QGELU) {
-        h4 hh;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { hh[r] = (half_t)v[r]; o[r] = (half_t)qgelu_f16((float)hh[r]); }
-        if (p.aux_out) *reinterpret_cast<h4*>(p.aux_out + off) = hh;
-      } else if (flags & EPI_DGELU) {
-        h4 hh = *reinterpret_cast<const h4*>(p.aux_in + off);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[r] * qgelu_grad((float)hh[r]));
-      } else if (flags & EPI_RESID) {
-        h4 rr = *reinterpret_cast<const h4*>(p.resid + off);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)((float)rr[r] + r16(v[r]));
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-      }
-      *reinterpret_cast<h4*>(p.C + off) = o;
+      if (n < p.N) *reinterpret_cast<f4*>(ws + (size_t)m * p.N + n) = acc[i][j];
     }
   }
 }
@@ -185,6 +231,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
   constexpr int LOADS = (BM + BN) * 8 / NTH;   // LDS-DMA instructions per thread per K-tile
+  static_assert(NT == 4, "the staged epilogue assumes 64 columns per wave");
   static_assert(LOADS == 8, "the counted vmcnt below assumes 8 loads per thread per tile");
 
   // current position (item, kt) and the decoded tile of the item
@@ -213,8 +260,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
   int pending_stores = 0;
   auto finish_item = [&]() {
     const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
-    pending_stores = !full ? 0 : ((p.splitk == 1 && (p.flags & EPI_QGELU) && p.aux_out) ? 2 * MT * NT : MT * NT);
-    epilogue<MT, NT>(p, acc, tm * BM + wm * (MT * 16) + (lane & 15), tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
+    if (p.splitk > 1) {
+      pending_stores = full ? MT * NT : 0;
+      epilogue_slab<MT, NT>(p, acc, tm * BM + wm * (MT * 16) + (lane & 15), tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
+    } else {
+      pending_stores = !full ? 0 : (((p.flags & EPI_QGELU) && p.aux_out) ? 4 * MT : 2 * MT);
+      epilogue_f16<MT>(p, acc, smem + 2 * STAGE_BYTES + wid * EPI_SCRATCH, tm * BM + wm * (MT * 16), tn * BN + wn * (NT * 16), lane);
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -234,8 +286,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
       const bool has_next = n_item < nitems;
       // This K-tile's LDS-DMA loads are OLDER than the previous item's epilogue stores, and vmcnt retires in
       // issue order: a counted wait lets those stores keep draining under this tile's MFMAs.
-      if (pending_stores >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-      else if (pending_stores == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      if (pending_stores == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else if (pending_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       pending_stores = 0;
       __builtin_amdgcn_s_barrier();
@@ -376,10 +428,12 @@ TileCfg pick_cfg(int M, int N, int K, bool allow_split) {
   c.bm = c.bn = big ? 256 : 128;
   c.splitk = 1;
   if (allow_split) {
+    // one resident workgroup per CU (two for the small tile): split K just far enough to fill the chip once,
+    // so the fp32 slab traffic (splitk * M * N * 8 bytes written + read) stays small
     long t = tiles_of(c.bm, c.bn);
-    long target = big ? 512 : 1024;          // blocks in flight: 2 resp. 4 per CU
-    if (t < target / 2 && nkt >= 8) {
-      long s = (target + t - 1) / t;
+    long slots = big ? 256 : 512;
+    if (t * 2 <= slots && nkt >= 8) {
+      long s = slots / t;
       if (s > nkt / 4) s = nkt / 4;
       c.splitk = (int)(s > 1 ? s : 1);
     }
@@ -389,7 +443,7 @@ TileCfg pick_cfg(int M, int N, int K, bool allow_split) {
 
 template <int BM, int BN, int WM, int WN>
 void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stream) {
-  constexpr int SMEM = 2 * (BM + BN) * BKT * 2;
+  constexpr int SMEM = 2 * (BM + BN) * BKT * 2 + WM * WN * EPI_SCRATCH;
   dim3 block(64 * WM * WN);
   if (SMEM > 64 * 1024) {
     static bool once = (hmmc_allow_lds((const void*)gemm_f16_kernel<true, true, BM, BN, WM, WN>, SMEM),
@@ -415,8 +469,8 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
                              int a_kmajor, int b_kmajor, const void* bias, const void* resid, void* aux_out,
                              const void* aux_in, int epilogue, void* workspace, size_t ws_bytes, hipStream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return HMMC_ERR_ARG;
-  if ((lda & 7) || (ldb & 7) || (ldc & 3) || (N & 7)) return HMMC_ERR_UNSUPPORTED;
-  if (((uintptr_t)A | (uintptr_t)B) & 15 || ((uintptr_t)C & 7)) return HMMC_ERR_UNSUPPORTED;
+  if ((lda & 7) || (ldb & 7) || (ldc & 7) || (N & 7)) return HMMC_ERR_UNSUPPORTED;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)resid | (uintptr_t)aux_in | (uintptr_t)aux_out) & 15) return HMMC_ERR_UNSUPPORTED;
   if ((a_kmajor || b_kmajor) && (K % BKT)) return HMMC_ERR_UNSUPPORTED;   // k tail of a k-major operand
   if (!a_kmajor && (M & 7)) return HMMC_ERR_UNSUPPORTED;
   if ((epilogue & EPI_BIAS) && !bias) return HMMC_ERR_ARG;

@@ -187,7 +187,8 @@ def attn_ref(qkv, nseq, L, H, causal):
 
 
 @pytest.mark.parametrize("nseq,L,H,causal", [(5, 50, 2, False), (3, 32, 8, True), (2, 45, 2, True), (7, 25, 2, True),
-                                             (4, 64, 12, False), (3, 17, 2, False)])
+                                             (4, 64, 12, False), (3, 17, 2, False), (3, 197, 2, False), (2, 77, 8, True),
+                                             (2, 130, 2, True), (1, 256, 1, False)])
 def test_attention_fwd_bwd(nseq, L, H, causal):
     D = H * 64
     qkv = rnd(nseq * L, 3 * D, scale=1.0)

@@ -148,7 +148,8 @@ def build(dims, use_temp=True, **tc):
     return model.to(DEV).train(), sd
 
 
-ENC = [("enc_tiny", synth.TINY, True), ("enc_tiny_notemp", synth.TINY, False), ("enc_b32", synth.VIT_B32, True)]
+ENC = [("enc_tiny", synth.TINY, True), ("enc_tiny_notemp", synth.TINY, False), ("enc_b32", synth.VIT_B32, True),
+       ("enc_tiny16", synth.TINY16, True)]       # patch 16: 197 tokens per frame (the ViT-B/16 attention path)
 
 
 @pytest.mark.parametrize("name,dims,use_temp", ENC)
