@@ -19,6 +19,8 @@ _C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c
 SIGNATURES = {
     "hmmc_gemm_f16_workspace": ("iii", "z"),
     "hmmc_gemm_f16": ("pppiiiiiiiippppipzp", "i"),
+    "hmmc_gemm_profile_start": ("", "i"),
+    "hmmc_gemm_profile_stop": ("ppp", "i"),
     "hmmc_layernorm_fwd": ("pppppppiilfip", "i"),
     "hmmc_layernorm_bwd_workspace": ("ii", "z"),
     "hmmc_layernorm_bwd": ("ppppppppppiilipzp", "i"),
@@ -45,7 +47,7 @@ SIGNATURES = {
     "hmmc_mt_chunk_elems": ("", "i"),
     "hmmc_mt_sumsq": ("ppipip", "i"),
     "hmmc_mt_clip_grad_norm": ("ppipifpp", "i"),
-    "hmmc_mt_bertadam": ("pppipip", "i"),
+    "hmmc_mt_bertadam": ("ppipipip", "i"),
     "hmmc_mt_ema": ("ppiffp", "i"),
     "hmmc_enqueue": ("ppiillp", "i"),
     "hmmc_bn_workspace": ("ii", "z"),
@@ -61,6 +63,11 @@ SIGNATURES = {
     "hmmc_gelu_erf_bwd": ("ppplp", "i"),
     "hmmc_ce_fwd": ("ppppppilp", "i"),
     "hmmc_ce_bwd": ("pppppilp", "i"),
+    "hmmc_tower_act_bytes": ("liiiii", "z"),
+    "hmmc_tower_bwd_scratch_bytes": ("lii", "z"),
+    "hmmc_tower_workspace_bytes": ("lii", "z"),
+    "hmmc_tower_fwd": ("ppppiiiiiiifipzp", "i"),
+    "hmmc_tower_bwd": ("pppppppiiiiiiipzp", "i"),
 }
 
 ERRORS = {-1: "invalid argument", -2: "unsupported shape/alignment", -3: "workspace too small", -4: "kernel launch failed"}

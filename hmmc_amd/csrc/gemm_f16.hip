@@ -460,6 +460,39 @@ void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stre
 
 }  // namespace
 
+// ---- optional live timing (bench.py): HIP events recorded on the launch stream around every hmmc_gemm_f16 call.
+// Process-wide and off by default; the only mutable state in the library, used by the benchmark alone.
+#include <vector>
+namespace {
+struct GemmProfRec { hipEvent_t e0, e1; double flops; int layout; };
+bool g_prof_on = false;
+std::vector<GemmProfRec> g_prof;
+}  // namespace
+
+extern "C" int hmmc_gemm_profile_start(void) {
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof.clear();
+  g_prof_on = true;
+  return HMMC_OK;
+}
+
+// out arrays of 3: layout 0 = forward (k-major x k-major), 1 = dgrad (k-major x m-major), 2 = wgrad (m-major A)
+extern "C" int hmmc_gemm_profile_stop(double* flops, double* seconds, long* launches) {
+  g_prof_on = false;
+  if (!flops || !seconds || !launches) return HMMC_ERR_ARG;
+  for (int i = 0; i < 3; ++i) { flops[i] = 0; seconds[i] = 0; launches[i] = 0; }
+  if (hipDeviceSynchronize() != hipSuccess) return HMMC_ERR_LAUNCH;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      flops[r.layout] += r.flops; seconds[r.layout] += ms * 1e-3; launches[r.layout] += 1;
+    }
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  return HMMC_OK;
+}
+
 extern "C" size_t hmmc_gemm_f16_workspace(int M, int N, int K) {
   TileCfg c = pick_cfg(M, N, K, true);
   return c.splitk > 1 ? (size_t)c.splitk * M * N * sizeof(float) : 0;
@@ -507,6 +540,12 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
   }();
   long resident = (long)num_cu * (cfg.bm == 256 ? 1 : 2);       // workgroups the LDS budget keeps resident
   dim3 grid((unsigned)(items < resident ? items : resident));
+  GemmProfRec rec{};
+  if (g_prof_on) {
+    (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
+    rec.flops = 2.0 * M * N * K; rec.layout = a_kmajor ? (b_kmajor ? 0 : 1) : 2;
+    (void)hipEventRecord(rec.e0, stream);
+  }
   if (cfg.bm == 256) launch_cfg<256, 256, 2, 4>(p, a_kmajor, b_kmajor, grid, stream);
   else launch_cfg<128, 128, 2, 2>(p, a_kmajor, b_kmajor, grid, stream);
   if (splitk > 1) {
@@ -515,5 +554,6 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, (half_t*)C, M, N,
                        ldc, splitk);
   }
+  if (g_prof_on) { (void)hipEventRecord(rec.e1, stream); g_prof.push_back(rec); }
   return hmmc_launch_status();
 }

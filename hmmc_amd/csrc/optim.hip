@@ -8,8 +8,9 @@
 // dtype with the reference's rounding points (fp16 params keep fp16 moments and round after every
 // tensor op), so fp16 results are bit-identical to the reference expression.
 //
-// tab  : int64 [T][8]  = { p, g, m, v (device pointers), numel, dtype (0 fp16 / 1 fp32), 0, 0 }
-// ftab : float [T][8]  = { lr_scheduled, weight_decay, b1, b2, eps, max_grad_norm, 1-b1, 1-b2 }
+// tab  : int64 [T][8]  = { p, g, m, v (device pointers), numel, dtype (0 fp16 / 1 fp32), group, 0 }
+// groups (by value, kernel argument): float [G][8] = { lr_scheduled, weight_decay, b1, b2, eps, max_grad_norm, 1-b1, 1-b2 }
+//        — the per-step scalars travel in the kernel argument buffer: no per-step host-to-device copy, no sync
 // chunk: int32 [C][2]  = { tensor index, chunk index }   (CHUNK elements per block)
 #include "common.h"
 
@@ -33,7 +34,7 @@ __device__ __forceinline__ float block_sum(float v) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// which: 1 = g (tab[.][1])
+// sumsq[t] += sum of g^2 over this chunk (16-byte loads; the scalar loop only handles a tensor's ragged tail)
 __global__ __launch_bounds__(256) void mt_sumsq_kernel(const long* __restrict__ tab, const int* __restrict__ chunk,
                                                        float* __restrict__ sumsq) {
   const int t = chunk[2 * blockIdx.x], ci = chunk[2 * blockIdx.x + 1];
@@ -43,10 +44,21 @@ __global__ __launch_bounds__(256) void mt_sumsq_kernel(const long* __restrict__ 
   float s = 0.f;
   if (e[5] == 0) {
     const half_t* g = reinterpret_cast<const half_t*>(e[1]);
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) { float x = (float)g[i]; s += x * x; }
+    const long iv = i0 + ((i1 - i0) & ~7L);
+    for (long i = i0 + threadIdx.x * 8; i < iv; i += 256 * 8) {
+      h8 v = *reinterpret_cast<const h8*>(g + i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float x = (float)v[j]; s += x * x; }
+    }
+    for (long i = iv + threadIdx.x; i < i1; i += 256) { float x = (float)g[i]; s += x * x; }
   } else {
     const float* g = reinterpret_cast<const float*>(e[1]);
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) { float x = g[i]; s += x * x; }
+    const long iv = i0 + ((i1 - i0) & ~3L);
+    for (long i = i0 + threadIdx.x * 4; i < iv; i += 256 * 4) {
+      f4 v = *reinterpret_cast<const f4*>(g + i);
+      s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    for (long i = iv + threadIdx.x; i < i1; i += 256) { float x = g[i]; s += x * x; }
   }
   s = block_sum(s);
   if (threadIdx.x == 0) atomicAdd(sumsq + t, s);
@@ -81,19 +93,34 @@ __global__ __launch_bounds__(256) void mt_scale_kernel(const long* __restrict__ 
   const long i0 = (long)ci * CHUNK, i1 = min(n, i0 + CHUNK);
   if (e[5] == 0) {
     half_t* g = reinterpret_cast<half_t*>(e[1]);
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) g[i] = (half_t)opq((float)g[i] * c);
+    const long iv = i0 + ((i1 - i0) & ~7L);
+    for (long i = i0 + threadIdx.x * 8; i < iv; i += 256 * 8) {
+      h8 v = *reinterpret_cast<h8*>(g + i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (half_t)opq((float)v[j] * c);
+      *reinterpret_cast<h8*>(g + i) = v;
+    }
+    for (long i = iv + threadIdx.x; i < i1; i += 256) g[i] = (half_t)opq((float)g[i] * c);
   } else {
     float* g = reinterpret_cast<float*>(e[1]);
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) g[i] = g[i] * c;
+    const long iv = i0 + ((i1 - i0) & ~3L);
+    for (long i = i0 + threadIdx.x * 4; i < iv; i += 256 * 4) {
+      f4 v = *reinterpret_cast<f4*>(g + i);
+      *reinterpret_cast<f4*>(g + i) = v * c;
+    }
+    for (long i = iv + threadIdx.x; i < i1; i += 256) g[i] = g[i] * c;
   }
 }
 
 // BertAdam.step for every tensor.  sumsq[t] = sum g^2 of the gradient as it stands (per-parameter clip).
-__global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict__ tab, const float* __restrict__ ftab,
+constexpr int MAX_GROUPS = 32;
+struct AdamGroups { float v[MAX_GROUPS][8]; };
+
+__global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict__ tab, AdamGroups groups,
                                                           const int* __restrict__ chunk, const float* __restrict__ sumsq) {
   const int t = chunk[2 * blockIdx.x], ci = chunk[2 * blockIdx.x + 1];
   const long* e = tab + (long)t * 8;
-  const float* f = ftab + (long)t * 8;
+  const float* f = groups.v[e[6]];
   const long n = e[4];
   const long i0 = (long)ci * CHUNK, i1 = min(n, i0 + CHUNK);
   const float lr = f[0], wd = f[1], b1 = f[2], b2 = f[3], eps = f[4], maxn = f[5];
@@ -112,20 +139,32 @@ __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict
       c = r16(maxn / r16(nrm + 1e-6f));
       c = c < 1.0f ? c : 1.0f;
     }
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-      float gi = (float)g[i];
-      if (maxn > 0.f) { gi = r16s(gi * c); g[i] = (half_t)gi; }
+    auto upd = [&](half_t& pp, half_t& gg, half_t& mm, half_t& vv) {
+      float gi = (float)gg;
+      if (maxn > 0.f) { gi = r16s(gi * c); gg = (half_t)gi; }
       // add_(g, alpha) is a true fma on the reference's CPU path; addcmul_ is (value*g)*g then an add
-      float mi = r16s(__fmaf_rn(ob1h, gi, r16s((float)m[i] * b1)));
-      float vi = r16s(r16s((float)v[i] * b2) + opq(opq(ob2 * gi) * gi));
-      float pi = (float)p[i];
+      float mi = r16s(__fmaf_rn(ob1h, gi, r16s((float)mm * b1)));
+      float vi = r16s(r16s((float)vv * b2) + opq(opq(ob2 * gi) * gi));
+      float pi = (float)pp;
       float u = r16s(mi / r16s(r16s(sqrtf(vi)) + eps));
       if (wd > 0.f) u = r16s(u + r16s(wd * pi));
       float uw = r16s(lr * u);
-      p[i] = (half_t)opq(pi - uw);
-      m[i] = (half_t)mi;
-      v[i] = (half_t)vi;
+      pp = (half_t)opq(pi - uw);
+      mm = (half_t)mi;
+      vv = (half_t)vi;
+    };
+    const long iv = i0 + ((i1 - i0) & ~7L);
+    for (long i = i0 + threadIdx.x * 8; i < iv; i += 256 * 8) {
+      h8 P = *reinterpret_cast<h8*>(p + i), G = *reinterpret_cast<h8*>(g + i);
+      h8 Mv = *reinterpret_cast<h8*>(m + i), Vv = *reinterpret_cast<h8*>(v + i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { half_t a = P[j], b = G[j], cc = Mv[j], d = Vv[j]; upd(a, b, cc, d); P[j] = a; G[j] = b; Mv[j] = cc; Vv[j] = d; }
+      *reinterpret_cast<h8*>(p + i) = P;
+      if (maxn > 0.f) *reinterpret_cast<h8*>(g + i) = G;
+      *reinterpret_cast<h8*>(m + i) = Mv;
+      *reinterpret_cast<h8*>(v + i) = Vv;
     }
+    for (long i = iv + threadIdx.x; i < i1; i += 256) upd(p[i], g[i], m[i], v[i]);
   } else {
     float* p = reinterpret_cast<float*>(e[0]);
     float* g = reinterpret_cast<float*>(e[1]);
@@ -136,17 +175,29 @@ __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict
       c = maxn / (sqrtf(sumsq[t]) + 1e-6f);
       c = c < 1.0f ? c : 1.0f;
     }
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-      float gi = g[i];
-      if (maxn > 0.f) { gi = gi * c; g[i] = gi; }
-      float mi = __fmaf_rn(ob1, gi, opq(m[i] * b1));
-      float vi = opq(v[i] * b2) + opq(opq(ob2 * gi) * gi);
+    auto upd = [&](float& pp, float& gg, float& mm, float& vv) {
+      float gi = gg;
+      if (maxn > 0.f) { gi = gi * c; gg = gi; }
+      float mi = __fmaf_rn(ob1, gi, opq(mm * b1));
+      float vi = opq(vv * b2) + opq(opq(ob2 * gi) * gi);
       float u = mi / opq(sqrtf(vi) + eps);
-      if (wd > 0.f) u = opq(u) + opq(wd * p[i]);
-      p[i] = p[i] - opq(lr * opq(u));
-      m[i] = mi;
-      v[i] = vi;
+      if (wd > 0.f) u = opq(u) + opq(wd * pp);
+      pp = pp - opq(lr * opq(u));
+      mm = mi;
+      vv = vi;
+    };
+    const long iv = i0 + ((i1 - i0) & ~3L);
+    for (long i = i0 + threadIdx.x * 4; i < iv; i += 256 * 4) {
+      f4 P = *reinterpret_cast<f4*>(p + i), G = *reinterpret_cast<f4*>(g + i);
+      f4 Mv = *reinterpret_cast<f4*>(m + i), Vv = *reinterpret_cast<f4*>(v + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float a = P[j], b = G[j], cc = Mv[j], d = Vv[j]; upd(a, b, cc, d); P[j] = a; G[j] = b; Mv[j] = cc; Vv[j] = d; }
+      *reinterpret_cast<f4*>(p + i) = P;
+      if (maxn > 0.f) *reinterpret_cast<f4*>(g + i) = G;
+      *reinterpret_cast<f4*>(m + i) = Mv;
+      *reinterpret_cast<f4*>(v + i) = Vv;
     }
+    for (long i = iv + threadIdx.x; i < i1; i += 256) upd(p[i], g[i], m[i], v[i]);
   }
 }
 
@@ -160,13 +211,27 @@ __global__ __launch_bounds__(256) void mt_ema_kernel(const long* __restrict__ ta
   if (e[5] == 0) {
     half_t* pk = reinterpret_cast<half_t*>(e[0]);
     const half_t* p = reinterpret_cast<const half_t*>(e[1]);
-    for (long i = i0 + threadIdx.x; i < i1; i += 256)
+    const long iv = i0 + ((i1 - i0) & ~7L);
+    for (long i = i0 + threadIdx.x * 8; i < iv; i += 256 * 8) {
+      h8 a = *reinterpret_cast<h8*>(pk + i), b = *reinterpret_cast<const h8*>(p + i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = (half_t)opq(r16s((float)a[j] * mom) + r16s((float)b[j] * one_minus));
+      *reinterpret_cast<h8*>(pk + i) = a;
+    }
+    for (long i = iv + threadIdx.x; i < i1; i += 256)
       pk[i] = (half_t)opq(r16s((float)pk[i] * mom) + r16s((float)p[i] * one_minus));
   } else {
     float* pk = reinterpret_cast<float*>(e[0]);
     const float* p = reinterpret_cast<const float*>(e[1]);
-    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-      float a = opq(pk[i] * mom), b = opq(p[i] * one_minus);   // three tensor ops, no fma contraction
+    const long iv = i0 + ((i1 - i0) & ~3L);
+    for (long i = i0 + threadIdx.x * 4; i < iv; i += 256 * 4) {
+      f4 a = *reinterpret_cast<f4*>(pk + i), b = *reinterpret_cast<const f4*>(p + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float x = opq(a[j] * mom), y = opq(b[j] * one_minus); a[j] = x + y; }   // three tensor ops, no fma
+      *reinterpret_cast<f4*>(pk + i) = a;
+    }
+    for (long i = iv + threadIdx.x; i < i1; i += 256) {
+      float a = opq(pk[i] * mom), b = opq(p[i] * one_minus);
       pk[i] = a + b;
     }
   }
@@ -205,12 +270,16 @@ extern "C" int hmmc_mt_clip_grad_norm(const long* tab, const int* chunk, int nch
   return hmmc_launch_status();
 }
 
-extern "C" int hmmc_mt_bertadam(const long* tab, const float* ftab, const int* chunk, int nchunks, float* sumsq, int T,
-                                hipStream_t stream) {
-  if (!tab || !ftab || !chunk || !sumsq || nchunks <= 0 || T <= 0) return HMMC_ERR_ARG;
+extern "C" int hmmc_mt_bertadam(const long* tab, const float* groups_host, int ngroups, const int* chunk, int nchunks,
+                                float* sumsq, int T, hipStream_t stream) {
+  if (!tab || !groups_host || !chunk || !sumsq || nchunks <= 0 || T <= 0) return HMMC_ERR_ARG;
+  if (ngroups <= 0 || ngroups > MAX_GROUPS) return HMMC_ERR_UNSUPPORTED;
+  AdamGroups groups;
+  for (int g = 0; g < ngroups; ++g)
+    for (int j = 0; j < 8; ++j) groups.v[g][j] = groups_host[g * 8 + j];
   hipMemsetAsync(sumsq, 0, (size_t)T * sizeof(float), stream);
   hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq);
-  hipLaunchKernelGGL(mt_bertadam_kernel, dim3(nchunks), dim3(256), 0, stream, tab, ftab, chunk, (const float*)sumsq);
+  hipLaunchKernelGGL(mt_bertadam_kernel, dim3(nchunks), dim3(256), 0, stream, tab, groups, chunk, (const float*)sumsq);
   return hmmc_launch_status();
 }
 

@@ -1,0 +1,204 @@
+// Native layer runtime: one C call runs every ResidualAttentionBlock of a tower, forward or backward
+// (reference modules/module_clip.py:231-268 for the fp16 CLIP towers, modules/module_cross.py:114-149 for the
+// fp32 temporal transformer).  It only SEQUENCES the kernels of this library on the caller's stream — ~20
+// launches per layer forward, ~30 backward — so the Python host issues 4 calls per step instead of ~1000 and
+// the launch stream stays ahead of the GPU even at 32 videos per GPU.  All memory is caller-owned:
+//   params  : nlayers x 12 pointers  (ln_1.w, ln_1.b, in_proj.w, in_proj.b, out_proj.w, out_proj.b,
+//                                      ln_2.w, ln_2.b, c_fc.w, c_fc.b, c_proj.w, c_proj.b)
+//   acts    : one slab of hmmc_tower_act_bytes() per layer (saved for backward); layout below
+//   scratch : hmmc_tower_bwd_scratch_bytes() for the backward's transient gradients
+//   grads   : nlayers x 12 pointers, written (not accumulated)
+#include "common.h"
+
+extern "C" {
+int hmmc_gemm_f16(const void*, const void*, void*, int, int, int, int, int, int, int, int, const void*, const void*, void*,
+                  const void*, int, void*, size_t, hipStream_t);
+size_t hmmc_gemm_f16_workspace(int, int, int);
+int hmmc_gemm_f32(const float*, const float*, float*, int, int, int, long, long, long, long, int, float, const float*,
+                  const float*, float*, const float*, int, hipStream_t);
+int hmmc_layernorm_fwd(const void*, const float*, const float*, void*, float*, float*, const int*, int, int, long, float, int,
+                       hipStream_t);
+int hmmc_layernorm_bwd(const void*, const void*, const float*, const float*, const float*, const void*, void*, float*, float*,
+                       const int*, int, int, long, int, void*, size_t, hipStream_t);
+size_t hmmc_layernorm_bwd_workspace(int, int);
+int hmmc_colsum(const void*, void*, int, int, long, int, int, int, void*, size_t, hipStream_t);
+size_t hmmc_colsum_workspace(int, int);
+int hmmc_attention_f16_fwd(const void*, void*, float*, int, int, int, int, hipStream_t);
+int hmmc_attention_f16_bwd(const void*, const void*, const float*, const void*, void*, int, int, int, int, hipStream_t);
+int hmmc_temporal_attention_fwd(const float*, float*, float*, int, int, int, int, hipStream_t);
+int hmmc_temporal_attention_bwd(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
+}
+
+namespace {
+
+enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8 };
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// activation slab of one layer (es = element size: 2 fp16 tower, 4 fp32 tower)
+struct Acts {
+  char *x, *ln1, *qkv, *att, *x1, *ln2, *h, *g;
+  float *m1, *r1, *m2, *r2, *stat;       // stat: lse [nseq,H,L] (fp16 tower) or probs [nseq,H,L,L] (fp32 tower)
+  size_t bytes;
+};
+
+Acts carve(char* base, long T, int D, int nseq, int L, int H, int es, bool f32) {
+  Acts a;
+  size_t td = al((size_t)T * D * es);
+  char* p = base;
+  a.x = p; p += td;
+  a.ln1 = p; p += td;
+  a.qkv = p; p += al((size_t)T * 3 * D * es);
+  a.att = p; p += td;
+  a.x1 = p; p += td;
+  a.ln2 = p; p += td;
+  a.h = p; p += al((size_t)T * 4 * D * es);
+  a.g = p; p += al((size_t)T * 4 * D * es);
+  a.m1 = (float*)p; p += al((size_t)T * 4);
+  a.r1 = (float*)p; p += al((size_t)T * 4);
+  a.m2 = (float*)p; p += al((size_t)T * 4);
+  a.r2 = (float*)p; p += al((size_t)T * 4);
+  a.stat = (float*)p; p += al((size_t)nseq * H * L * (f32 ? L : 1) * 4);
+  a.bytes = (size_t)(p - base);
+  return a;
+}
+
+inline int linear(bool f32, const void* x, const void* w, void* y, int M, int N, int K, const void* bias, const void* resid,
+                  void* aux_out, int epi, void* ws, size_t wsb, hipStream_t s) {
+  if (f32)
+    return hmmc_gemm_f32((const float*)x, (const float*)w, (float*)y, M, N, K, K, 1, 1, K, N, 1.0f, (const float*)bias,
+                         (const float*)resid, (float*)aux_out, nullptr, epi | (bias ? EPI_BIAS : 0) | (resid ? EPI_RESID : 0), s);
+  return hmmc_gemm_f16(x, w, y, M, N, K, K, K, N, 1, 1, bias, resid, aux_out, nullptr,
+                       epi | (bias ? EPI_BIAS : 0) | (resid ? EPI_RESID : 0), nullptr, 0, s);
+}
+// dx[M,K'] = dy[M,N'] w[N',K']
+inline int dgrad(bool f32, const void* dy, const void* w, void* dx, int M, int Np, int Kp, const void* aux_in, int epi,
+                 hipStream_t s) {
+  if (f32)
+    return hmmc_gemm_f32((const float*)dy, (const float*)w, (float*)dx, M, Kp, Np, Np, 1, Kp, 1, Kp, 1.0f, nullptr, nullptr,
+                         nullptr, (const float*)aux_in, epi, s);
+  return hmmc_gemm_f16(dy, w, dx, M, Kp, Np, Np, Kp, Kp, 1, 0, nullptr, nullptr, nullptr, aux_in, epi, nullptr, 0, s);
+}
+// dW[N',K'] = dy[T,N']^T x[T,K']
+inline int wgrad(bool f32, const void* dy, const void* x, void* dw, int T, int Np, int Kp, void* ws, size_t wsb, hipStream_t s) {
+  if (f32)
+    return hmmc_gemm_f32((const float*)dy, (const float*)x, (float*)dw, Np, Kp, T, 1, Np, Kp, 1, Kp, 1.0f, nullptr, nullptr,
+                         nullptr, nullptr, 0, s);
+  size_t need = hmmc_gemm_f16_workspace(Np, Kp, T);
+  return hmmc_gemm_f16(dy, x, dw, Np, Kp, T, Np, Kp, Kp, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, need <= wsb ? ws : nullptr,
+                       need <= wsb ? wsb : 0, s);
+}
+
+#define CK(call) do { int rc_ = (call); if (rc_ != 0) return rc_; } while (0)
+
+}  // namespace
+
+extern "C" size_t hmmc_tower_act_bytes(long tokens, int D, int nseq, int L, int heads, int fp32) {
+  return carve(nullptr, tokens, D, nseq, L, heads, fp32 ? 4 : 2, fp32 != 0).bytes;
+}
+
+// transient gradients of the backward: dh [T,4D], dqkv [T,3D], dln [T,D], dx1 [T,D], ping/pong dx [T,D] x2
+extern "C" size_t hmmc_tower_bwd_scratch_bytes(long tokens, int D, int fp32) {
+  size_t es = fp32 ? 4 : 2;
+  return al((size_t)tokens * 4 * D * es) + al((size_t)tokens * 3 * D * es) + 4 * al((size_t)tokens * D * es);
+}
+
+extern "C" size_t hmmc_tower_workspace_bytes(long tokens, int D, int fp32) {
+  size_t w = hmmc_layernorm_bwd_workspace((int)tokens, D);
+  size_t c = hmmc_colsum_workspace((int)tokens, 4 * D);
+  if (c > w) w = c;
+  if (!fp32) {
+    size_t g = hmmc_gemm_f16_workspace(3 * D, D, (int)tokens);
+    size_t g2 = hmmc_gemm_f16_workspace(4 * D, D, (int)tokens);
+    size_t g3 = hmmc_gemm_f16_workspace(D, 4 * D, (int)tokens);
+    size_t g4 = hmmc_gemm_f16_workspace(D, D, (int)tokens);
+    if (g2 > g) g = g2;
+    if (g3 > g) g = g3;
+    if (g4 > g) g = g4;
+    if (g > w) w = g;
+  }
+  return al(w);
+}
+
+// y = tower(x).  keep_acts: acts holds nlayers slabs (training); otherwise one slab is reused (key encoders, eval).
+extern "C" int hmmc_tower_fwd(const void* x, void* y, const void* const* params, void* acts, int keep_acts, int nseq, int L,
+                              int heads, int D, int nlayers, int causal, float eps, int fp32, void* workspace,
+                              size_t ws_bytes, hipStream_t s) {
+  if (!x || !y || !params || !acts || nseq <= 0 || L <= 0 || heads <= 0 || nlayers <= 0 || D != heads * 64) return HMMC_ERR_ARG;
+  const bool f32 = fp32 != 0;
+  const int es = f32 ? 4 : 2, dt = f32 ? 1 : 0;
+  const long T = (long)nseq * L;
+  const size_t slab = hmmc_tower_act_bytes(T, D, nseq, L, heads, fp32);
+  const void* cur = x;
+  for (int i = 0; i < nlayers; ++i) {
+    const void* const* P = params + (size_t)i * 12;
+    Acts a = carve((char*)acts + (keep_acts ? (size_t)i * slab : 0), T, D, nseq, L, heads, es, f32);
+    const void* xin = cur;
+    CK(hmmc_layernorm_fwd(xin, (const float*)P[0], (const float*)P[1], a.ln1, a.m1, a.r1, nullptr, (int)T, D, D, eps, dt, s));
+    CK(linear(f32, a.ln1, P[2], a.qkv, (int)T, 3 * D, D, P[3], nullptr, nullptr, 0, workspace, ws_bytes, s));
+    if (f32) CK(hmmc_temporal_attention_fwd((const float*)a.qkv, (float*)a.att, a.stat, nseq, L, heads, causal, s));
+    else CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+    CK(linear(f32, a.att, P[4], a.x1, (int)T, D, D, P[5], xin, nullptr, 0, workspace, ws_bytes, s));
+    CK(hmmc_layernorm_fwd(a.x1, (const float*)P[6], (const float*)P[7], a.ln2, a.m2, a.r2, nullptr, (int)T, D, D, eps, dt, s));
+    CK(linear(f32, a.ln2, P[8], a.g, (int)T, 4 * D, D, P[9], nullptr, keep_acts ? a.h : nullptr, EPI_QGELU, workspace, ws_bytes, s));
+    // output of this layer: next layer's saved input slot, or y for the last layer.  Without saved activations one
+    // slab is reused: the output alternates between the x and h slots (h is dead once c_proj has read g, and the
+    // next layer's input is dead before its own c_fc rewrites h).
+    void* out = y;
+    if (i + 1 < nlayers) out = keep_acts ? carve((char*)acts + (size_t)(i + 1) * slab, T, D, nseq, L, heads, es, f32).x
+                                         : (void*)(((i & 1) == 0) ? a.x : a.h);
+    CK(linear(f32, a.g, P[10], out, (int)T, D, 4 * D, P[11], a.x1, nullptr, 0, workspace, ws_bytes, s));
+    cur = out;
+  }
+  return HMMC_OK;
+}
+
+// dx = d tower / d x (dy given), grads[nlayers*12] written.  x0 is the tower input given to hmmc_tower_fwd.
+extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads,
+                              const void* acts, void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal,
+                              int fp32, void* workspace, size_t ws_bytes, hipStream_t s) {
+  if (!dy || !dx || !x0 || !params || !grads || !acts || !scratch || nseq <= 0 || L <= 0 || nlayers <= 0 || D != heads * 64)
+    return HMMC_ERR_ARG;
+  const bool f32 = fp32 != 0;
+  const int es = f32 ? 4 : 2, dt = f32 ? 1 : 0;
+  const long T = (long)nseq * L;
+  const size_t slab = hmmc_tower_act_bytes(T, D, nseq, L, heads, fp32);
+  char* sp = (char*)scratch;
+  void* dh = sp; sp += al((size_t)T * 4 * D * es);
+  void* dqkv = sp; sp += al((size_t)T * 3 * D * es);
+  void* dln = sp; sp += al((size_t)T * D * es);
+  void* dx1 = sp; sp += al((size_t)T * D * es);
+  void* ping[2];
+  ping[0] = sp; sp += al((size_t)T * D * es);
+  ping[1] = sp;
+  const void* g_in = dy;
+  for (int i = nlayers - 1; i >= 0; --i) {
+    const void* const* P = params + (size_t)i * 12;
+    void* const* G = grads + (size_t)i * 12;
+    Acts a = carve((char*)acts + (size_t)i * slab, T, D, nseq, L, heads, es, f32);
+    const void* xin = i == 0 ? x0 : (const void*)a.x;
+    void* g_out = i == 0 ? dx : ping[i & 1];
+    // MLP: x2 = x1 + c_proj(QuickGELU(c_fc(ln2)))
+    CK(wgrad(f32, g_in, a.g, G[10], (int)T, D, 4 * D, workspace, ws_bytes, s));
+    CK(hmmc_colsum(g_in, G[11], (int)T, D, D, dt, dt, 0, workspace, ws_bytes, s));
+    CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_DGELU, s));
+    CK(wgrad(f32, dh, a.ln2, G[8], (int)T, 4 * D, D, workspace, ws_bytes, s));
+    CK(hmmc_colsum(dh, G[9], (int)T, 4 * D, 4 * D, dt, dt, 0, workspace, ws_bytes, s));
+    CK(dgrad(f32, dh, P[8], dln, (int)T, 4 * D, D, nullptr, 0, s));
+    CK(hmmc_layernorm_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], nullptr, (int)T, D, D,
+                          dt, workspace, ws_bytes, s));
+    // attention: x1 = x + out_proj(attn(in_proj(ln1)))
+    CK(wgrad(f32, dx1, a.att, G[4], (int)T, D, D, workspace, ws_bytes, s));
+    CK(hmmc_colsum(dx1, G[5], (int)T, D, D, dt, dt, 0, workspace, ws_bytes, s));
+    CK(dgrad(f32, dx1, P[4], dln, (int)T, D, D, nullptr, 0, s));                 // datt (reuses dln)
+    if (f32) CK(hmmc_temporal_attention_bwd((const float*)a.qkv, a.stat, (const float*)dln, (float*)dqkv, nseq, L, heads, s));
+    else CK(hmmc_attention_f16_bwd(a.qkv, a.att, a.stat, dln, dqkv, nseq, L, heads, causal, s));
+    CK(wgrad(f32, dqkv, a.ln1, G[2], (int)T, 3 * D, D, workspace, ws_bytes, s));
+    CK(hmmc_colsum(dqkv, G[3], (int)T, 3 * D, 3 * D, dt, dt, 0, workspace, ws_bytes, s));
+    CK(dgrad(f32, dqkv, P[2], dln, (int)T, 3 * D, D, nullptr, 0, s));
+    CK(hmmc_layernorm_bwd(dln, xin, (const float*)P[0], a.m1, a.r1, dx1, g_out, (float*)G[0], (float*)G[1], nullptr, (int)T, D, D,
+                          dt, workspace, ws_bytes, s));
+    g_in = g_out;
+  }
+  return HMMC_OK;
+}

@@ -82,64 +82,61 @@ class TextEmbedFn(torch.autograd.Function):
         return None, dtable, dpos
 
 
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep):
+    """Run all layers through the native layer runtime (hmmc_tower_fwd).  Returns (y, acts slab or None)."""
+    from ._lib import call, ptr, query
+    T, D = x.shape
+    nl = len(params) // PER_LAYER
+    slab = query("hmmc_tower_act_bytes", T, D, nseq, L, heads, int(fp32))
+    acts = torch.empty(slab * (nl if keep else 1), dtype=torch.uint8, device=x.device)
+    wsb = query("hmmc_tower_workspace_bytes", T, D, int(fp32))
+    ws = ops.workspace(wsb, x.device, "tower")
+    y = torch.empty_like(x)
+    call("hmmc_tower_fwd", ptr(x), ptr(y), _ptr_array(params), ptr(acts), int(keep), nseq, L, heads, D, nl, int(causal),
+         float(eps), int(fp32), ptr(ws), wsb)
+    return y, (acts if keep else None)
+
+
+def _tower_backward(dy, x0, params, acts, nseq, L, heads, causal, fp32):
+    from ._lib import call, ptr, query
+    T, D = x0.shape
+    nl = len(params) // PER_LAYER
+    grads = [torch.empty_like(p) for p in params]
+    scratch = torch.empty(query("hmmc_tower_bwd_scratch_bytes", T, D, int(fp32)), dtype=torch.uint8, device=x0.device)
+    wsb = query("hmmc_tower_workspace_bytes", T, D, int(fp32))
+    ws = ops.workspace(wsb, x0.device, "tower")
+    dx = torch.empty_like(x0)
+    call("hmmc_tower_bwd", ptr(dy), ptr(dx), ptr(x0), _ptr_array(params), _ptr_array(grads), ptr(acts), ptr(scratch), nseq, L,
+         heads, D, nl, int(causal), int(fp32), ptr(ws), wsb)
+    return dx, grads
+
+
 class ClipTransformerFn(torch.autograd.Function):
-    """All layers of a CLIP tower in one autograd node (fp16 activations, fp32 LayerNorm statistics)."""
+    """All layers of a CLIP tower in one autograd node and ONE native call each way (fp16 activations, fp32
+    LayerNorm statistics); the per-layer activations live in a single slab laid out by the library."""
 
     @staticmethod
     def forward(ctx, x, nseq, L, heads, causal, *params):
-        nl = len(params) // PER_LAYER
-        T, D = x.shape
-        saved = []
         keep = any(ctx.needs_input_grad)       # momentum (key) encoders and eval run under no_grad
-        for i in range(nl):
-            (l1w, l1b, inw, inb, ow, ob, l2w, l2b, fcw, fcb, pw, pb) = params[i * PER_LAYER:(i + 1) * PER_LAYER]
-            ln1, m1, r1 = ops.layernorm_fwd(x, l1w, l1b, 1e-5)
-            qkv = ops.gemm_f16(ln1, inw, T, 3 * D, D, bias=inb)
-            att, lse = ops.attention_f16_fwd(qkv, nseq, L, heads, causal)
-            x1 = ops.gemm_f16(att, ow, T, D, D, bias=ob, resid=x)
-            ln2, m2, r2 = ops.layernorm_fwd(x1, l2w, l2b, 1e-5)
-            g, h = ops.gemm_f16(ln2, fcw, T, 4 * D, D, bias=fcb, epilogue=ops.EPI_QGELU, want_aux=True)
-            x2 = ops.gemm_f16(g, pw, T, D, 4 * D, bias=pb, resid=x1)
-            if keep:
-                saved.append([x, m1, r1, ln1, qkv, att, lse, x1, m2, r2, ln2, h, g])
-            x = x2
-        ctx.saved = saved
-        ctx.params = params
+        x = x.contiguous()
+        for prm in params:
+            if not prm.is_contiguous():
+                raise ValueError("tower parameters must be contiguous")
+        y, acts = _tower_forward(x, params, nseq, L, heads, causal, 1e-5, False, keep)
+        ctx.acts, ctx.x0, ctx.params = acts, (x if keep else None), params
         ctx.cfg = (nseq, L, heads, causal)
-        return x
+        return y
 
     @staticmethod
-    def backward(ctx, dx):
+    def backward(ctx, dy):
         nseq, L, heads, causal = ctx.cfg
-        params = ctx.params
-        nl = len(params) // PER_LAYER
-        grads = [None] * len(params)
-        dx = dx.contiguous()
-        for i in reversed(range(nl)):
-            (l1w, l1b, inw, inb, ow, ob, l2w, l2b, fcw, fcb, pw, pb) = params[i * PER_LAYER:(i + 1) * PER_LAYER]
-            x, m1, r1, ln1, qkv, att, lse, x1, m2, r2, ln2, h, g = ctx.saved[i]
-            ctx.saved[i] = None
-            d_pw = _wgrad16(dx, g)
-            d_pb = ops.colsum(dx)
-            dh = _dgrad16(dx, pw, aux_in=h, epilogue=ops.EPI_DGELU)
-            del g
-            d_fcw = _wgrad16(dh, ln2)
-            d_fcb = ops.colsum(dh)
-            dln2 = _dgrad16(dh, fcw)
-            del dh, h, ln2
-            dx1, d_l2w, d_l2b = ops.layernorm_bwd(dln2, x1, l2w, m2, r2, dres=dx)
-            d_ow = _wgrad16(dx1, att)
-            d_ob = ops.colsum(dx1)
-            datt = _dgrad16(dx1, ow)
-            dqkv = ops.attention_f16_bwd(qkv, att, lse, datt, nseq, L, heads, causal)
-            del att, qkv, datt
-            d_inw = _wgrad16(dqkv, ln1)
-            d_inb = ops.colsum(dqkv)
-            dln1 = _dgrad16(dqkv, inw)
-            dx, d_l1w, d_l1b = ops.layernorm_bwd(dln1, x, l1w, m1, r1, dres=dx1)
-            grads[i * PER_LAYER:(i + 1) * PER_LAYER] = [d_l1w, d_l1b, d_inw, d_inb, d_ow, d_ob, d_l2w, d_l2b, d_fcw,
-                                                        d_fcb, d_pw, d_pb]
-        ctx.saved = None
+        dx, grads = _tower_backward(dy.contiguous(), ctx.x0, ctx.params, ctx.acts, nseq, L, heads, causal, False)
+        ctx.acts = ctx.x0 = None
         return (dx, None, None, None, None, *grads)
 
 
@@ -171,39 +168,6 @@ class LnProjFn(torch.autograd.Function):
         return dx, None, dlw, dlb, dproj
 
 
-def _f32_block_fwd(x, rows, seqs, L, H, causal, eps, p):
-    (l1w, l1b, inw, inb, ow, ob, l2w, l2b, fcw, fcb, pw, pb) = p
-    ln1, m1, r1 = ops.layernorm_fwd(x, l1w, l1b, eps)
-    qkv = ops.linear_f32(ln1, inw, bias=inb)
-    att, probs = ops.attention_f32_fwd(qkv, seqs, L, H, causal)
-    x1 = ops.linear_f32(att, ow, bias=ob, resid=x)
-    ln2, m2, r2 = ops.layernorm_fwd(x1, l2w, l2b, eps)
-    g, h = ops.linear_f32(ln2, fcw, bias=fcb, epilogue=ops.EPI_QGELU, want_aux=True)
-    x2 = ops.linear_f32(g, pw, bias=pb, resid=x1)
-    return x2, [x, m1, r1, ln1, qkv, att, probs, x1, m2, r2, ln2, h, g]
-
-
-def _f32_block_bwd(dx, saved, seqs, L, H, p):
-    (l1w, l1b, inw, inb, ow, ob, l2w, l2b, fcw, fcb, pw, pb) = p
-    x, m1, r1, ln1, qkv, att, probs, x1, m2, r2, ln2, h, g = saved
-    d_pw = ops.wgrad_f32(dx, g)
-    d_pb = ops.colsum(dx)
-    dh = ops.dgrad_f32(dx, pw, aux_in=h, epilogue=ops.EPI_DGELU)
-    d_fcw = ops.wgrad_f32(dh, ln2)
-    d_fcb = ops.colsum(dh)
-    dln2 = ops.dgrad_f32(dh, fcw)
-    dx1, d_l2w, d_l2b = ops.layernorm_bwd(dln2, x1, l2w, m2, r2, dres=dx)
-    d_ow = ops.wgrad_f32(dx1, att)
-    d_ob = ops.colsum(dx1)
-    datt = ops.dgrad_f32(dx1, ow)
-    dqkv = ops.attention_f32_bwd(qkv, probs, datt, seqs, L, H)
-    d_inw = ops.wgrad_f32(dqkv, ln1)
-    d_inb = ops.colsum(dqkv)
-    dln1 = ops.dgrad_f32(dqkv, inw)
-    dx0, d_l1w, d_l1b = ops.layernorm_bwd(dln1, x, l1w, m1, r1, dres=dx1)
-    return dx0, [d_l1w, d_l1b, d_inw, d_inb, d_ow, d_ob, d_l2w, d_l2b, d_fcw, d_fcb, d_pw, d_pb]
-
-
 class TemporalFn(torch.autograd.Function):
     """video_emb = mean_f normalise( TemporalTransformer(u + pos) + u ); fp32 throughout, TF-style LN eps 1e-12."""
 
@@ -212,18 +176,16 @@ class TemporalFn(torch.autograd.Function):
         b, F, E = u.shape
         u2 = u.contiguous().view(b * F, E)
         nl = len(params) // PER_LAYER
-        saved = []
+        keep = any(ctx.needs_input_grad)
+        acts = x0 = None
         if nl:
-            x = ops.add_rowbias(u2, pos_table, F)
-            for i in range(nl):
-                x, s = _f32_block_fwd(x, b * F, b, F, heads, False, 1e-12, params[i * PER_LAYER:(i + 1) * PER_LAYER])
-                saved.append(s)
+            x0 = ops.add_rowbias(u2, pos_table, F)
+            x, acts = _tower_forward(x0, params, b, F, heads, False, 1e-12, True, keep)
             out, norms = ops.temporal_pool_fwd(x, u2, b, F, E)
         else:
             x = u2
             out, norms = ops.temporal_pool_fwd(x, None, b, F, E)
-        ctx.saved = saved
-        ctx.params = params
+        ctx.acts, ctx.x0, ctx.params = acts, x0, params
         ctx.fin = (x, u2, norms, pos_table)
         ctx.cfg = (b, F, E, heads)
         return out
@@ -234,19 +196,14 @@ class TemporalFn(torch.autograd.Function):
         x, u2, norms, pos_table = ctx.fin
         params = ctx.params
         nl = len(params) // PER_LAYER
-        grads = [None] * len(params)
         dvf = ops.temporal_pool_bwd(x, u2 if nl else None, norms, dout.contiguous(), b, F, E)
         if not nl:
             return dvf.view(b, F, E), None, None
-        dx = dvf
-        for i in reversed(range(nl)):
-            dx, g = _f32_block_bwd(dx, ctx.saved[i], b, F, heads, params[i * PER_LAYER:(i + 1) * PER_LAYER])
-            ctx.saved[i] = None
-            grads[i * PER_LAYER:(i + 1) * PER_LAYER] = g
+        dx, grads = _tower_backward(dvf, ctx.x0, params, ctx.acts, b, F, heads, False, True)
         dpos = torch.zeros_like(pos_table)
         dpos[:F] = ops.colsum(dx.view(b, F * E)).view(F, E)
         du = dx + dvf                                   # through (u + pos) and through the residual
-        ctx.saved = None
+        ctx.acts = ctx.x0 = None
         return (du.view(b, F, E), None, dpos, *grads)
 
 

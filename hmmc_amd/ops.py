@@ -15,28 +15,21 @@ EPI_BIAS, EPI_RESID, EPI_QGELU, EPI_DGELU = 1, 2, 4, 8
 
 _ws_cache = {}
 
-# optional live timing of the dominant kernel (bench.py): HIP events on the launch stream around every
-# hmmc_gemm_f16 call, keyed by operand layout
-_gemm_prof = None
-
-
 def gemm_profile_start():
-    global _gemm_prof
-    _gemm_prof = []
+    """bench.py: time every hmmc_gemm_f16 launch (also those issued by the native tower runtime) with HIP events
+    recorded on the launch stream."""
+    _lib.load().hmmc_gemm_profile_start()
 
 
 def gemm_profile_stop():
     """-> {layout: {"flops", "seconds", "launches"}} (synchronises)."""
-    global _gemm_prof
-    rec, _gemm_prof = _gemm_prof or [], None
-    torch.cuda.synchronize()
-    out = {}
-    for key, flops, e0, e1 in rec:
-        d = out.setdefault(key, {"flops": 0.0, "seconds": 0.0, "launches": 0})
-        d["flops"] += flops
-        d["seconds"] += e0.elapsed_time(e1) * 1e-3
-        d["launches"] += 1
-    return out
+    import ctypes
+    flops, secs, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_long * 3)()
+    rc = _lib.load().hmmc_gemm_profile_stop(flops, secs, n)
+    if rc:
+        raise RuntimeError(f"hmmc_gemm_profile_stop failed: {rc}")
+    names = ("fwd_kk", "dgrad_km", "wgrad_mm")
+    return {names[i]: {"flops": flops[i], "seconds": secs[i], "launches": n[i]} for i in range(3) if n[i]}
 
 
 def workspace(nbytes, device, tag="default"):
@@ -80,15 +73,8 @@ def gemm_f16(a, b, M, N, K, a_kmajor=True, b_kmajor=True, bias=None, resid=None,
         assert tuple(aux_in.shape) == (M, N)
     wsb = 0 if epilogue else query("hmmc_gemm_f16_workspace", M, N, K)
     ws = workspace(wsb, a.device, "gemm") if wsb else None
-    if _gemm_prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     call("hmmc_gemm_f16", ptr(a), ptr(b), ptr(c), M, N, K, a.shape[1], b.shape[1], N, int(a_kmajor), int(b_kmajor),
          ptr(bias), ptr(resid), ptr(aux_out), ptr(aux_in), epilogue, ptr(ws), wsb)
-    if _gemm_prof is not None:
-        e1.record()
-        key = ("fwd_kk" if b_kmajor else "dgrad_km") if a_kmajor else ("wgrad_mm" if not b_kmajor else "mk")
-        _gemm_prof.append((key, 2.0 * M * N * K, e0, e1))
     return (c, aux_out) if want_aux else c
 
 

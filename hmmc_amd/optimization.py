@@ -7,6 +7,7 @@ starting at 0 so the first update uses lr 0 under warm-up.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import numpy as np
@@ -47,17 +48,18 @@ class _TensorTable:
         self.chunk_elems = load().hmmc_mt_chunk_elems()
 
     def build(self, rows):
-        """rows: list of (ptr0, ptr1, ptr2, ptr3, numel, dtype_flag)."""
+        """rows: list of (ptr0, ptr1, ptr2, ptr3, numel, dtype_flag[, group]).  The tables are staged through pinned
+        memory and copied asynchronously: building them never blocks the host behind queued GPU work."""
         key = tuple(rows)
         if key != self.key:
             arr = np.zeros((len(rows), 8), dtype=np.int64)
-            arr[:, :6] = np.asarray(rows, dtype=np.int64)
+            arr[:, :len(rows[0])] = np.asarray(rows, dtype=np.int64)
             nch = (arr[:, 4] + self.chunk_elems - 1) // self.chunk_elems
             tidx = np.repeat(np.arange(len(rows)), nch)
             cidx = np.concatenate([np.arange(n) for n in nch]) if len(rows) else np.zeros(0, dtype=np.int64)
             chunks = np.stack([tidx, cidx], axis=1).astype(np.int32)
-            self.tab = torch.from_numpy(arr).to(self.device, non_blocking=True)
-            self.chunk = torch.from_numpy(chunks).to(self.device, non_blocking=True)
+            self.tab = torch.from_numpy(arr).pin_memory().to(self.device, non_blocking=True)
+            self.chunk = torch.from_numpy(chunks).pin_memory().to(self.device, non_blocking=True)
             self.nchunks = int(chunks.shape[0])
             self.T = len(rows)
             self.sumsq = torch.zeros(len(rows), dtype=torch.float32, device=self.device)
@@ -140,7 +142,7 @@ class BertAdam(Optimizer):
                 loss = closure()
         rows, frows = [], []
         dev = None
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -158,10 +160,13 @@ class BertAdam(Optimizer):
                 else:
                     lr_s = group["lr"]
                 dev = p.device
+                # one hyper-parameter row per distinct (group, step count): parameters of a group normally share both
+                hp = (lr_s, group["weight_decay"], group["b1"], group["b2"], group["e"], group["max_grad_norm"],
+                      1 - group["b1"], 1 - group["b2"])
+                if not frows or frows[-1] != hp:
+                    frows.append(hp)
                 rows.append((p.data_ptr(), p.grad.data_ptr(), state["next_m"].data_ptr(), state["next_v"].data_ptr(),
-                             p.numel(), _dtype_flag(p)))
-                frows.append((lr_s, group["weight_decay"], group["b1"], group["b2"], group["e"], group["max_grad_norm"],
-                              1 - group["b1"], 1 - group["b2"]))
+                             p.numel(), _dtype_flag(p), len(frows) - 1))
                 state["step"] += 1
         if not rows:
             return loss
@@ -169,7 +174,9 @@ class BertAdam(Optimizer):
             raise RuntimeError("hmmc_amd.BertAdam runs on the GPU only (no CPU fallback)")
         if self._table is None:
             self._table = _TensorTable(dev)
+        if len(frows) > 32:
+            raise ValueError("BertAdam (HIP): more than 32 distinct (group, step) hyper-parameter rows")
         tbl = self._table.build(rows)
-        ftab = torch.tensor(frows, dtype=torch.float32).to(dev, non_blocking=True)
-        call("hmmc_mt_bertadam", ptr(tbl.tab), ptr(ftab), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T)
+        hp_host = (ctypes.c_float * (8 * len(frows)))(*[x for row in frows for x in row])
+        call("hmmc_mt_bertadam", ptr(tbl.tab), hp_host, len(frows), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T)
         return loss

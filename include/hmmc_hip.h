@@ -44,6 +44,10 @@ typedef void* hmmc_stream_t; /* hipStream_t */
  * Without an epilogue, small-output/long-K problems (weight gradients) are split over K into
  * fp32 slabs in `workspace` (hmmc_gemm_f16_workspace bytes; may be NULL to disable). */
 size_t hmmc_gemm_f16_workspace(int M, int N, int K);
+/* Benchmark-only live timing of every hmmc_gemm_f16 launch with HIP events on the launch stream; stop() synchronises and
+ * returns, per operand layout (0 forward, 1 dgrad, 2 wgrad), the summed 2MNK flops, seconds and launch counts. */
+int hmmc_gemm_profile_start(void);
+int hmmc_gemm_profile_stop(double* flops, double* seconds, long* launches);
 int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor,
                   int b_kmajor, const void* bias, const void* resid, void* aux_out, const void* aux_in, int epilogue,
                   void* workspace, size_t ws_bytes, hmmc_stream_t stream);
@@ -128,8 +132,9 @@ int hmmc_temporal_attention_fwd(const float* qkv, float* out, float* probs, int 
 int hmmc_temporal_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int b, int F, int H,
                                 hmmc_stream_t stream);
 
-/* Multi-tensor kernels.  tab: int64 [T][8] = {p, g, m, v device pointers, numel, dtype (0 fp16, 1 fp32), 0, 0};
- * ftab: float [T][8] = {scheduled lr, weight_decay, b1, b2, eps, max_grad_norm, 1-b1, 1-b2};
+/* Multi-tensor kernels.  tab: int64 [T][8] = {p, g, m, v device pointers, numel, dtype (0 fp16, 1 fp32), group, 0};
+ * groups_host: HOST float [ngroups <= 32][8] = {scheduled lr, weight_decay, b1, b2, eps, max_grad_norm, 1-b1, 1-b2}, passed to the
+ * kernel by value (tab[t][6] = group of tensor t): the per-step scalars need no device copy;
  * chunk: int32 [nchunks][2] = {tensor index, chunk index}, hmmc_mt_chunk_elems() elements per chunk;
  * sumsq: float [T] scratch. */
 int hmmc_mt_chunk_elems(void);
@@ -138,8 +143,8 @@ int hmmc_mt_sumsq(const long* tab, const int* chunk, int nchunks, float* sumsq, 
 int hmmc_mt_clip_grad_norm(const long* tab, const int* chunk, int nchunks, float* sumsq, int T, float max_norm, float* out,
                            hmmc_stream_t stream);
 /* BertAdam.step (modules/optimization.py:103-168) for every tensor, including its per-parameter clip. */
-int hmmc_mt_bertadam(const long* tab, const float* ftab, const int* chunk, int nchunks, float* sumsq, int T,
-                     hmmc_stream_t stream);
+int hmmc_mt_bertadam(const long* tab, const float* groups_host, int ngroups, const int* chunk, int nchunks, float* sumsq,
+                     int T, hmmc_stream_t stream);
 /* _momentum_update (modules/modeling.py:238-242); tab rows = {p_k, p, 0, 0, numel, dtype}. */
 int hmmc_mt_ema(const long* tab, const int* chunk, int nchunks, float momentum, float one_minus_momentum,
                 hmmc_stream_t stream);
@@ -180,6 +185,21 @@ int hmmc_ce_fwd(const float* logits, const long* labels, float* lse, float* rowl
                 hmmc_stream_t stream);
 int hmmc_ce_bwd(float* logits, const long* labels, const float* lse, const float* grad_out, const float* count, int R, long V,
                 hmmc_stream_t stream);
+
+/* Native layer runtime: all ResidualAttentionBlocks of a tower in one call (modules/module_clip.py:231-268 fp16 CLIP
+ * towers, fp32 = 0, eps 1e-5; modules/module_cross.py:114-149 fp32 temporal transformer, fp32 = 1, eps 1e-12).
+ * params / grads: nlayers x 12 pointers in the order ln_1.{w,b}, attn.in_proj_{weight,bias}, attn.out_proj.{weight,bias},
+ * ln_2.{w,b}, mlp.c_fc.{weight,bias}, mlp.c_proj.{weight,bias}.  acts: hmmc_tower_act_bytes() per layer when keep_acts
+ * (training), one slab otherwise.  The backward needs hmmc_tower_bwd_scratch_bytes() of scratch; both need
+ * hmmc_tower_workspace_bytes().  Only sequences this library's kernels on `stream`. */
+size_t hmmc_tower_act_bytes(long tokens, int D, int nseq, int L, int heads, int fp32);
+size_t hmmc_tower_bwd_scratch_bytes(long tokens, int D, int fp32);
+size_t hmmc_tower_workspace_bytes(long tokens, int D, int fp32);
+int hmmc_tower_fwd(const void* x, void* y, const void* const* params, void* acts, int keep_acts, int nseq, int L, int heads,
+                   int D, int nlayers, int causal, float eps, int fp32, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads, const void* acts,
+                   void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal, int fp32, void* workspace,
+                   size_t ws_bytes, hmmc_stream_t stream);
 
 #ifdef __cplusplus
 }
