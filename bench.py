@@ -113,11 +113,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)      # rehearsal on fewer GPUs than ranks
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("HMMC_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; gloo only for rehearsals
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     from hmmc_amd import ops, synth
     from hmmc_amd.modeling import BirdModel
@@ -131,7 +134,7 @@ def main():
     optimizer = prep_optimizer(model, cfg, t_total=1000)
     net = model
     if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank,
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_dev], output_device=local_dev,
                                                         find_unused_parameters=False, gradient_as_bucket_view=False)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     res = synth.NAMED[args.clip].image_res
