@@ -95,6 +95,19 @@ def cpu_baseline(frames, length, seconds=20.0):
                       f"(fwd+bwd+clip+BertAdam), torch CPU {torch.__version__}"}
 
 
+def recorded_traffic(args, per_gpu_batch):
+    """HBM bytes per gemm_f16_kernel launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB units,
+    separate rocprofv3 --pmc runs of this same command; profiles/r01_gemm_f16_hbm_traffic.json).  The counters cannot
+    be read from inside the process, so the figure is only reported for the workload it was collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_gemm_f16_hbm_traffic.json")
+    if not (per_gpu_batch == 256 and args.frames == 12 and args.length == 32 and args.clip == "ViT-B/32"
+            and os.path.exists(path)):
+        return None
+    with open(path) as f:
+        rec = json.load(f)
+    return round(rec["hbm_traffic_per_launch_bytes"]), "profiles/r01_gemm_f16_hbm_traffic.json (rocprofv3 --pmc, separate passes)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,12 +195,16 @@ def main():
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         roof = {"bound": "mfma", "kernel": "gemm_f16_kernel (fp16 MFMA GEMM, all operand layouts)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None, "traffic_unit": "bytes/launch",
                 "launches_per_step": launches // max(args.steps, 1),
                 "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),
                 "gemm_share_of_step": round(secs / dt, 4),
                 "by_layout": {k: {"tflops": round(p["flops"] / p["seconds"] / 1e12, 1), "launches": p["launches"],
                                   "avg_us": round(p["seconds"] / p["launches"] * 1e6, 2)} for k, p in prof.items()}}
+        rec = recorded_traffic(args, b)
+        if rec is not None:
+            roof["traffic"], roof["traffic_source"] = rec
+            roof["algorithmic_bytes_per_launch"] = round(sum(p.get("bytes", 0) for p in prof.values()) / max(launches, 1)) or None
         out = {"metric": "video-text pairs/sec (whole node), B=256 F=12 224^2", "value": round(value, 2),
                "unit": "video-text pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

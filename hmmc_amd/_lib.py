@@ -20,7 +20,7 @@ SIGNATURES = {
     "hmmc_gemm_f16_workspace": ("iii", "z"),
     "hmmc_gemm_f16": ("pppiiiiiiiippppipzp", "i"),
     "hmmc_gemm_profile_start": ("", "i"),
-    "hmmc_gemm_profile_stop": ("ppp", "i"),
+    "hmmc_gemm_profile_stop": ("pppp", "i"),
     "hmmc_layernorm_fwd": ("pppppppiilfip", "i"),
     "hmmc_layernorm_bwd_workspace": ("ii", "z"),
     "hmmc_layernorm_bwd": ("ppppppppppiilipzp", "i"),

@@ -464,7 +464,7 @@ void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stre
 // Process-wide and off by default; the only mutable state in the library, used by the benchmark alone.
 #include <vector>
 namespace {
-struct GemmProfRec { hipEvent_t e0, e1; double flops; int layout; };
+struct GemmProfRec { hipEvent_t e0, e1; double flops, bytes; int layout; };
 bool g_prof_on = false;
 std::vector<GemmProfRec> g_prof;
 }  // namespace
@@ -477,15 +477,16 @@ extern "C" int hmmc_gemm_profile_start(void) {
 }
 
 // out arrays of 3: layout 0 = forward (k-major x k-major), 1 = dgrad (k-major x m-major), 2 = wgrad (m-major A)
-extern "C" int hmmc_gemm_profile_stop(double* flops, double* seconds, long* launches) {
+// bytes = algorithmic operand bytes (A + B + C and the epilogue's bias / residual / aux tensors, each touched once)
+extern "C" int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seconds, long* launches) {
   g_prof_on = false;
-  if (!flops || !seconds || !launches) return HMMC_ERR_ARG;
-  for (int i = 0; i < 3; ++i) { flops[i] = 0; seconds[i] = 0; launches[i] = 0; }
+  if (!flops || !bytes || !seconds || !launches) return HMMC_ERR_ARG;
+  for (int i = 0; i < 3; ++i) { flops[i] = 0; bytes[i] = 0; seconds[i] = 0; launches[i] = 0; }
   if (hipDeviceSynchronize() != hipSuccess) return HMMC_ERR_LAUNCH;
   for (auto& r : g_prof) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
-      flops[r.layout] += r.flops; seconds[r.layout] += ms * 1e-3; launches[r.layout] += 1;
+      flops[r.layout] += r.flops; bytes[r.layout] += r.bytes; seconds[r.layout] += ms * 1e-3; launches[r.layout] += 1;
     }
     (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
@@ -543,7 +544,11 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
   GemmProfRec rec{};
   if (g_prof_on) {
     (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
-    rec.flops = 2.0 * M * N * K; rec.layout = a_kmajor ? (b_kmajor ? 0 : 1) : 2;
+    rec.flops = 2.0 * M * N * K;
+    double mn = (double)M * N;
+    rec.bytes = 2.0 * ((double)M * K + (double)N * K + mn) + ((epilogue & EPI_BIAS) ? 2.0 * N : 0.0) +
+                2.0 * mn * (((epilogue & EPI_RESID) ? 1 : 0) + ((epilogue & EPI_DGELU) ? 1 : 0) + (aux_out ? 1 : 0));
+    rec.layout = a_kmajor ? (b_kmajor ? 0 : 1) : 2;
     (void)hipEventRecord(rec.e0, stream);
   }
   if (cfg.bm == 256) launch_cfg<256, 256, 2, 4>(p, a_kmajor, b_kmajor, grid, stream);

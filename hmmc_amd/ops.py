@@ -22,14 +22,14 @@ def gemm_profile_start():
 
 
 def gemm_profile_stop():
-    """-> {layout: {"flops", "seconds", "launches"}} (synchronises)."""
+    """-> {layout: {"flops", "bytes", "seconds", "launches"}} (synchronises)."""
     import ctypes
-    flops, secs, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_long * 3)()
-    rc = _lib.load().hmmc_gemm_profile_stop(flops, secs, n)
+    flops, nbytes, secs, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_long * 3)()
+    rc = _lib.load().hmmc_gemm_profile_stop(flops, nbytes, secs, n)
     if rc:
         raise RuntimeError(f"hmmc_gemm_profile_stop failed: {rc}")
     names = ("fwd_kk", "dgrad_km", "wgrad_mm")
-    return {names[i]: {"flops": flops[i], "seconds": secs[i], "launches": n[i]} for i in range(3) if n[i]}
+    return {names[i]: {"flops": flops[i], "bytes": nbytes[i], "seconds": secs[i], "launches": n[i]} for i in range(3) if n[i]}
 
 
 def workspace(nbytes, device, tag="default"):

@@ -45,9 +45,9 @@ typedef void* hmmc_stream_t; /* hipStream_t */
  * fp32 slabs in `workspace` (hmmc_gemm_f16_workspace bytes; may be NULL to disable). */
 size_t hmmc_gemm_f16_workspace(int M, int N, int K);
 /* Benchmark-only live timing of every hmmc_gemm_f16 launch with HIP events on the launch stream; stop() synchronises and
- * returns, per operand layout (0 forward, 1 dgrad, 2 wgrad), the summed 2MNK flops, seconds and launch counts. */
+ * returns, per operand layout (0 forward, 1 dgrad, 2 wgrad), the summed 2MNK flops, algorithmic operand bytes, seconds and launch counts. */
 int hmmc_gemm_profile_start(void);
-int hmmc_gemm_profile_stop(double* flops, double* seconds, long* launches);
+int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seconds, long* launches);
 int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor,
                   int b_kmajor, const void* bias, const void* resid, void* aux_out, const void* aux_in, int epilogue,
                   void* workspace, size_t ws_bytes, hmmc_stream_t stream);
