@@ -48,11 +48,11 @@ __device__ __forceinline__ float r16(float x) { return (float)(half_t)x; }
 // (modules/module_clip.py:226-228: x * sigmoid(1.702 * x) on an fp16 tensor).
 __device__ __forceinline__ float qgelu_f16(float h) {
   float t = r16(1.702f * h);
-  float s = r16(1.0f / (1.0f + __expf(-t)));
+  float s = r16(__builtin_amdgcn_rcpf(1.0f + __expf(-t)));      // v_rcp_f32: 1 ulp, far inside the fp16 rounding that follows
   return r16(h * s);
 }
 // d/dh [h * sigmoid(1.702 h)]
 __device__ __forceinline__ float qgelu_grad(float h) {
-  float s = 1.0f / (1.0f + __expf(-1.702f * h));
+  float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * h));
   return s * (1.0f + 1.702f * h * (1.0f - s));
 }

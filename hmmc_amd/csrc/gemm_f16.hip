@@ -23,6 +23,7 @@
 // ds_read_b64_tr_b16 hardware transpose).  Two LDS stages; the prefetch of tile t+1 stays in
 // flight across the compute of tile t (counted vmcnt + raw s_barrier).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -37,7 +38,15 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc;
   int flags, splitk, ktps;
   unsigned a_bytes, b_bytes;
+  int stag_grp, stag_nph, stag_ticks;     // start stagger: ((lid / grp) % nph) * ticks / nph  (100 MHz ticks)
 };
+
+#ifdef HMMC_GEMM_STAMPS
+__device__ unsigned long long g_stamps[8][2][64];
+#define STAMP(IDX) do { if (bid < 8 && (wid & 3) == 0 && lane == 0 && (IDX) < 64) g_stamps[bid][wid >> 2][IDX] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(IDX) do {} while (0)
+#endif
 
 // ---- LDS-DMA staging -------------------------------------------------------------------------
 // k-major tile image: [128 rows][8 chunks of 16 B]; phys chunk = logical ^ ((row >> 1) & 7)
@@ -67,6 +76,40 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
   }
 }
 
+// ---- half-tile staging for the ping-pong schedule (256x256 tile) ------------------------------------
+// A 256-row operand tile is held as two 16 KiB half images of 128 rows.  Half h holds, for every wave, the
+// rows that wave needs in its half-h quadrants, so that a half image is dead (and can be restaged) as soon
+// as one phase of the K-tile has read it:
+//   A: LDS row r of half h  <->  tile row (r >> 6) * 128 + h * 64 + (r & 63)    (wave wm reads r = wm*64 ..+63)
+//   B: LDS row r of half h  <->  tile row (r >> 5) *  64 + h * 32 + (r & 31)    (wave wn reads r = wn*32 ..+31)
+// so each wave still owns 128 x 64 CONTIGUOUS outputs.  k-major half image: [128 rows][8 chunks];
+// m-major: [64 k-rows][16 chunks]; same XOR swizzles as above.  The per-thread part of the source offset is
+// loop-invariant (half_vbase), the per-half part is wave-uniform.
+template <bool KMAJ, bool IS_A>
+__device__ __forceinline__ unsigned half_vbase(int tid, int ld) {
+  if (KMAJ) {
+    int r = tid >> 3;                                        // 0..63: LDS row within a pass
+    int logical = (tid & 7) ^ ((r >> 1) & 7);
+    int row = IS_A ? r : ((r >> 5) * 64 + (r & 31));
+    return ((unsigned)row * (unsigned)ld + (unsigned)(logical * 8)) * 2u;
+  } else {
+    int krow = tid >> 4, pc = tid & 15;                      // 32 k-rows per pass
+    int f = ((krow & 3) << 2) | ((krow >> 2) & 3);
+    int logical = pc ^ f;
+    int row = IS_A ? ((logical >> 3) * 128 + (logical & 7) * 8) : ((logical >> 2) * 64 + (logical & 3) * 8);
+    return ((unsigned)krow * (unsigned)ld + (unsigned)row) * 2u;
+  }
+}
+
+// two LDS-DMA loads per thread (512 threads x 16 B x 2 = 16 KiB); soff = 0x80000000 makes both read as zero
+template <bool KMAJ>
+__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, char* lds_half, int wid, unsigned vbase,
+                                           unsigned soff, int ld) {
+  const unsigned pass = (KMAJ ? 128u : 32u) * (unsigned)ld * 2u;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_half + wid * 1024), 16, vbase + soff, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_half + 8192 + wid * 1024), 16, vbase + soff + pass, 0, 0, 0);
+}
+
 // ---- fragment reads --------------------------------------------------------------------------
 // returns the 8 halves op[row0 + (lane & 15)][ks*32 + 8*(lane >> 4) + j], j = 0..7
 template <bool KMAJ, int R>
@@ -94,50 +137,111 @@ __device__ __forceinline__ h8 read_frag(const char* lds_tile, int row0, int ks, 
 }
 
 // ---- epilogue -------------------------------------------------------------------------------------
-// MFMA layout: lane (c = lane & 15, g = lane >> 4) owns C[m0 + c][16j + 4g .. +3] of every 16x16 tile j.
-// Written straight from that layout a store instruction touches 16 rows x 32 B (16 partial lines) and the
-// tile's 128 KiB leave the CU at the store-ISSUE rate.  Instead each wave restages its 16 x 64 half-precision
-// strip through a private 2.3 KiB LDS scratch (144-byte rows: conflict-free b64 writes, aligned b128 reads) so
-// that every global access is 16 B per lane and covers 8 rows x 128 contiguous bytes (whole lines), for the
-// output and equally for the residual / pre-activation operand it reads.  No workgroup barrier: the scratch is
-// wave-private and LDS operations of one wave execute in order.
-constexpr int EPI_ROW = 144;                   // bytes per scratch row
-constexpr int EPI_SCRATCH = 16 * EPI_ROW;      // per wave
+// MFMA layout: lane (c = lane & 15, g = lane >> 4) owns C[m0 + c][16j + 4g .. +3] of every 16x16 tile j: four
+// 8-byte pieces per row.  Stored like that an instruction touches 16 rows x 32 B; measured per-CU store rates
+// (scratch/ubench/store_bw.hip): 8 rows x 128 B per instruction 130 GB/s, 16 rows x 64 B 33 GB/s.  Two register
+// exchanges bring the strip into the 8 x 128 B shape without touching LDS:
+//  1. v_permlane16_swap (odd 16-lane rows of one register <-> even rows of another) applied to (piece j = 2q,
+//     piece j = 2q + 1) hands every lane its neighbour's (g ^ 1) piece of the same tile: the lane then holds 8
+//     consecutive columns, 16 bytes, per column pair q, at column offset 32q + 16 (g & 1) + 8 (g >> 1).
+//  2. a DPP row rotate by 8 swaps q = 1 of rows c < 8 with q = 0 of rows c >= 8: afterwards lanes c < 8 hold the
+//     q = 0 pieces of rows c and c + 8, lanes c >= 8 the q = 1 pieces of rows c - 8 and c.  Store t = 0, 1 writes
+//     rows 8t .. 8t + 7, each row's 128 bytes from 8 lanes.
+// Both exchanges are involutions, so the residual / pre-activation operand is read with the same full-line
+// accesses and brought back into the MFMA layout.  All operand loads of the tile are issued before the first strip is
+// processed; nothing waits between strips.
+__device__ __forceinline__ void swap_rows(unsigned& x, unsigned& y) {
+  auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  x = r[0]; y = r[1];
+}
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
-template <int MT>
-__device__ __forceinline__ void epilogue_f16(const GemmArgs& p, f4 (&acc)[MT][4], char* scr, int m_base, int n0, int lane) {
-  const int flags = p.flags;
+__device__ __forceinline__ u4 join(h4 a, h4 b) {
+  u2 x = __builtin_bit_cast(u2, a), y = __builtin_bit_cast(u2, b);
+  return u4{x[0], x[1], y[0], y[1]};
+}
+// piece of tile 2q and piece of tile 2q+1 (MFMA layout)  <->  8 consecutive columns of the lane's row
+__device__ __forceinline__ void swap_pair(u4& v) {
+  unsigned a = v[0], b = v[1], c = v[2], d = v[3];
+  swap_rows(a, c);
+  swap_rows(b, d);
+  v = u4{a, b, c, d};
+}
+// (x = q0 piece, y = q1 piece) of this lane's row  <->  the lane's two 16-byte pieces in store order.
+// row_ror:8 reads lane c ^ 8 of the same 16-lane row; the bank mask picks which half of the row is written:
+// lanes c >= 8 take the neighbour's y into x, lanes c < 8 the neighbour's x into y.
+__device__ __forceinline__ void to_store_order(u4& x, u4& y) {
+  u4 nx, ny;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    nx[e] = (unsigned)__builtin_amdgcn_update_dpp((int)x[e], (int)y[e], 0x128, 0xf, 0xc, false);
+    ny[e] = (unsigned)__builtin_amdgcn_update_dpp((int)y[e], (int)x[e], 0x128, 0xf, 0x3, false);
+  }
+  x = nx; y = ny;
+}
+
+// F >= 0: the epilogue flags at compile time; F < 0: p.flags at run time
+template <int MT, int F>
+__device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
+  const int flags = F >= 0 ? F : p.flags;
   const int c = lane & 15, g = lane >> 4;
-  const int io_row = lane >> 3, io_chunk = lane & 7;
-  const int n_io = n0 + io_chunk * 8;
-  const bool n_ok = n_io < p.N;                                   // N % 8 == 0: a 16-byte piece is all-in or all-out
+  const int n_l = 32 * (c >> 3) + 16 * (g & 1) + 8 * (g >> 1);   // this lane's 8 columns within the wave's 64
+  const bool n_ok = n0 + n_l < p.N;                              // N % 8 == 0: a 16-byte piece is all-in or all-out
+  const int r_l = c & 7;                                         // this lane's row within a group of 8
+  const bool full = m_base + 16 * MT <= p.M && n0 + 64 <= p.N;   // wave-uniform: no masks on interior tiles
+  // global address = uniform 64-bit base (scalar registers) + 32-bit lane offset
+  const unsigned voff = ((unsigned)r_l * (unsigned)p.ldc + (unsigned)n_l) * 2u;
+  const size_t row8 = (size_t)p.ldc * 16u;                       // bytes between row r and row r + 8
   h4 bias[4];
   if (flags & EPI_BIAS) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int n = n0 + 16 * j + 4 * g;
-      bias[j] = n < p.N ? *reinterpret_cast<const h4*>(p.bias + n) : h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+      bias[j] = *reinterpret_cast<const h4*>(p.bias + (n < p.N ? n : 0));
     }
   }
-  const half_t* src = (flags & EPI_DGELU) ? p.aux_in : ((flags & EPI_RESID) ? p.resid : nullptr);
+  const bool has_src = flags & (EPI_DGELU | EPI_RESID);
+  const char* src = reinterpret_cast<const char*>((flags & EPI_DGELU) ? p.aux_in : p.resid);
+  constexpr int HB = MT > 4 ? 4 : MT;            // strips whose operand loads are in flight together (32 VGPRs)
+  u4 rin[HB][2];
+  const bool two = (flags & EPI_QGELU) && p.aux_out;
+  auto store2 = [&](half_t* dst, int i, u4 o0, u4 o1) {
+    char* sb = reinterpret_cast<char*>(dst) + ((size_t)(m_base + 16 * i) * p.ldc + n0) * 2u;
+    if (full) {
+      *reinterpret_cast<u4*>(sb + voff) = o0;
+      *reinterpret_cast<u4*>(sb + row8 + voff) = o1;
+    } else {
+      const int m0 = m_base + 16 * i + r_l;
+      if (m0 < p.M && n_ok) *reinterpret_cast<u4*>(sb + voff) = o0;
+      if (m0 + 8 < p.M && n_ok) *reinterpret_cast<u4*>(sb + row8 + voff) = o1;
+    }
+  };
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m0 = m_base + i * 16;
     h4 in[4];
-    if (src) {                                   // coalesced read of the 16 x 64 operand strip
+    if (has_src) {
+      if (i % HB == 0) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        int r = io_row + 8 * t, m = m0 + r;
-        h8 v;
+        for (int ii = 0; ii < HB; ++ii) {
+          const char* sb = src + ((size_t)(m_base + 16 * (i + ii)) * p.ldc + n0) * 2u;
+          if (full) {
+            rin[ii][0] = *reinterpret_cast<const u4*>(sb + voff);
+            rin[ii][1] = *reinterpret_cast<const u4*>(sb + row8 + voff);
+          } else {                               // clamped, never masked: rows / columns outside are not stored
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
-        if (m < p.M && n_ok) v = *reinterpret_cast<const h8*>(src + (size_t)m * p.ldc + n_io);
-        *reinterpret_cast<h8*>(scr + r * EPI_ROW + io_chunk * 16) = v;
+            for (int t = 0; t < 2; ++t) {
+              const int m = min(m_base + 16 * (i + ii) + 8 * t + r_l, p.M - 1);
+              rin[ii][t] = *reinterpret_cast<const u4*>(src + ((size_t)m * p.ldc + (n_ok ? n0 + n_l : 0)) * 2u);
+            }
+          }
+        }
       }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) in[j] = *reinterpret_cast<const h4*>(scr + c * EPI_ROW + (16 * j + 4 * g) * 2);
-      __builtin_amdgcn_wave_barrier();
+      u4 x = rin[i % HB][0], y = rin[i % HB][1];
+      to_store_order(x, y);                                      // involution: store order -> (q0, q1) of the own row
+      swap_pair(x); swap_pair(y);
+      in[0] = __builtin_bit_cast(h4, u2{x[0], x[1]}); in[1] = __builtin_bit_cast(h4, u2{x[2], x[3]});
+      in[2] = __builtin_bit_cast(h4, u2{y[0], y[1]}); in[3] = __builtin_bit_cast(h4, u2{y[2], y[3]});
     }
     h4 out[4], pre[4];
 #pragma unroll
@@ -161,21 +265,30 @@ __device__ __forceinline__ void epilogue_f16(const GemmArgs& p, f4 (&acc)[MT][4]
         for (int r = 0; r < 4; ++r) out[j][r] = (half_t)v[r];
       }
     }
-    const int npass = ((flags & EPI_QGELU) && p.aux_out) ? 2 : 1;
-    for (int pass = 0; pass < npass; ++pass) {   // pass 1 writes the pre-activation to aux_out
-      half_t* dst = pass == 0 ? p.C : p.aux_out;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<h4*>(scr + c * EPI_ROW + (16 * j + 4 * g) * 2) = pass == 0 ? out[j] : pre[j];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        int r = io_row + 8 * t, m = m0 + r;
-        h8 v = *reinterpret_cast<const h8*>(scr + r * EPI_ROW + io_chunk * 16);
-        if (m < p.M && n_ok) *reinterpret_cast<h8*>(dst + (size_t)m * p.ldc + n_io) = v;
-      }
-      __builtin_amdgcn_wave_barrier();
+    {
+      u4 o0 = join(out[0], out[1]), o1 = join(out[2], out[3]);
+      swap_pair(o0); swap_pair(o1);
+      to_store_order(o0, o1);
+      store2(p.C, i, o0, o1);
     }
+    if (two) {                                   // the pre-activation, for the backward pass
+      u4 o0 = join(pre[0], pre[1]), o1 = join(pre[2], pre[3]);
+      swap_pair(o0); swap_pair(o1);
+      to_store_order(o0, o1);
+      store2(p.aux_out, i, o0, o1);
+    }
+  }
+}
+
+template <int MT>
+__device__ __forceinline__ void epilogue_f16(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
+  switch (p.flags) {                            // the combinations the towers use get straight-line code
+    case 0: epilogue_impl<MT, 0>(p, acc, m_base, n0, lane); break;
+    case EPI_BIAS: epilogue_impl<MT, EPI_BIAS>(p, acc, m_base, n0, lane); break;
+    case EPI_BIAS | EPI_RESID: epilogue_impl<MT, EPI_BIAS | EPI_RESID>(p, acc, m_base, n0, lane); break;
+    case EPI_BIAS | EPI_QGELU: epilogue_impl<MT, EPI_BIAS | EPI_QGELU>(p, acc, m_base, n0, lane); break;
+    case EPI_DGELU: epilogue_impl<MT, EPI_DGELU>(p, acc, m_base, n0, lane); break;
+    default: epilogue_impl<MT, -1>(p, acc, m_base, n0, lane); break;
   }
 }
 
@@ -199,7 +312,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, f4 (&acc)[MT][N
 // Persistent: the grid is sized to the chip and every workgroup walks work items (output tile x K-split)
 // item, item + gridDim, ...  The LDS-DMA prefetch runs one K-tile ahead across item boundaries, so the
 // first tile of the next output tile is already in flight while this one's epilogue stores drain.
-template <bool AK, bool BK, int BM, int BN, int WM, int WN>
+template <bool AK, bool BK, int BM, int BN, int WM, int WN, bool PP = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NTH = 64 * WM * WN;
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
@@ -241,8 +354,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
   int tm = tile / ntn, tn = tile - tm * ntn;
   int kt = split * p.ktps, kt_end = min(nkt, kt + p.ktps);     // host guarantees kt < kt_end for every item
   int buf = 0;
-  stage_tile<AK, BM, NTH>(ra, smem, wid, tid, tm * BM, kt * BKT, p.lda);
-  stage_tile<BK, BN, NTH>(rb, smem + A_BYTES, wid, tid, tn * BN, kt * BKT, p.ldb);
+  if constexpr (!PP) {
+    stage_tile<AK, BM, NTH>(ra, smem, wid, tid, tm * BM, kt * BKT, p.lda);
+    stage_tile<BK, BN, NTH>(rb, smem + A_BYTES, wid, tid, tn * BN, kt * BKT, p.ldb);
+  }
 
   auto next_pos = [&](int& n_item, int& n_split, int& n_tm, int& n_tn, int& n_kt, int& n_end) {
     n_item = item; n_split = split; n_tm = tm; n_tn = tn; n_kt = kt + 1; n_end = kt_end;
@@ -265,7 +380,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
       epilogue_slab<MT, NT>(p, acc, tm * BM + wm * (MT * 16) + (lane & 15), tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
     } else {
       pending_stores = !full ? 0 : (((p.flags & EPI_QGELU) && p.aux_out) ? 4 * MT : 2 * MT);
-      epilogue_f16<MT>(p, acc, smem + 2 * STAGE_BYTES + wid * EPI_SCRATCH, tm * BM + wm * (MT * 16), tn * BN + wn * (NT * 16), lane);
+      epilogue_f16<MT>(p, acc, tm * BM + wm * (MT * 16), tn * BN + wn * (NT * 16), lane);
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -273,7 +388,124 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
       for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
   };
 
-  if constexpr (MT == 8 && NT == 4) {
+  if constexpr (MT == 8 && NT == 4 && PP) {
+    // ---- 256x256 tile, ping-pong schedule.  The two waves of a SIMD are wid and wid + 4, i.e. the wm = 0 and wm = 1
+    // waves of one wn.  A K-tile is 4 phases of 16 MFMAs (one 64x32 quadrant x K = 64); each phase is a LOAD segment
+    // (LDS fragment reads for this phase + the LDS-DMA of one half-tile of a later K-tile), a barrier, a MATRIX
+    // segment, a barrier.  The wm = 1 group runs one barrier behind, so on every SIMD one wave's matrix segment
+    // sits beside its partner's load segment.
+    //   phase   reads (ds_read)      MFMA quadrant     stages (LDS-DMA, 2 loads/thread)
+    //     1     A0 (8) + B0 (4)      (a0, b0)          B1 of K-tile t+1
+    //     2     B1 (4)               (a0, b1)          A1 of K-tile t+1
+    //     3     A1 (8)               (a1, b1)          A0 of K-tile t+2
+    //     4     - (B0 kept)          (a1, b0)          B0 of K-tile t+2, then s_waitcnt vmcnt(4)
+    // WAR: a half image is restaged two phases or more after the phase that last read it, so with the groups one
+    // barrier apart every read has retired (lgkmcnt before that phase's MFMAs) before the DMA is even issued.
+    // RAW: the vmcnt(4) of phase 4 (everything but A0/B0 of t+2 has landed) precedes the barrier both groups
+    // pass before any wave reads K-tile t+1.  Past the last K-tile the DMA is still issued, out of range
+    // (reads as zero into a dead image), so the count of 4 stays exact.
+    constexpr int HALF = 128 * BKT * 2;
+    const unsigned vA = half_vbase<AK, true>(tid, p.lda), vB = half_vbase<BK, false>(tid, p.ldb);
+    int s_item = item, s_tm = tm, s_tn = tn, s_kt = kt, s_end = kt_end, s_buf = 0;
+    bool s_ok = true;
+    auto s_advance = [&]() {
+      ++s_kt; s_buf ^= 1;
+      if (s_kt >= s_end) {
+        s_item += nblk;
+        s_ok = s_item < nitems;
+        if (s_ok) {
+          int sp = s_item / ntiles, t2 = s_item - sp * ntiles;
+          s_tm = t2 / ntn; s_tn = t2 - s_tm * ntn;
+          s_kt = sp * p.ktps; s_end = min(nkt, s_kt + p.ktps);
+        }
+      }
+    };
+    auto stage_a = [&](int h) {
+      unsigned so = AK ? ((unsigned)(s_tm * BM + h * 64) * (unsigned)p.lda + (unsigned)(s_kt * BKT)) * 2u
+                       : ((unsigned)(s_kt * BKT) * (unsigned)p.lda + (unsigned)(s_tm * BM + h * 64)) * 2u;
+      if (!s_ok) so = 0x80000000u;
+      stage_half<AK>(ra, smem + s_buf * (4 * HALF) + h * HALF, wid, vA, so, p.lda);
+    };
+    auto stage_b = [&](int h) {
+      unsigned so = BK ? ((unsigned)(s_tn * BN + h * 32) * (unsigned)p.ldb + (unsigned)(s_kt * BKT)) * 2u
+                       : ((unsigned)(s_kt * BKT) * (unsigned)p.ldb + (unsigned)(s_tn * BN + h * 32)) * 2u;
+      if (!s_ok) so = 0x80000000u;
+      stage_half<BK>(rb, smem + s_buf * (4 * HALF) + (2 + h) * HALF, wid, vB, so, p.ldb);
+    };
+#define HMMC_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); \
+                        __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HMMC_MM(I0, J0, BF) do { __builtin_amdgcn_s_setprio(1); \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+      acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[ks][j], af[ks][i], acc[I0 + i][J0 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0); } while (0)
+    if (p.stag_ticks > 0) {
+      const unsigned long long t_go = __builtin_amdgcn_s_memrealtime() +
+                                      (unsigned long long)(((lid / p.stag_grp) % p.stag_nph) * p.stag_ticks / p.stag_nph);
+      while (__builtin_amdgcn_s_memrealtime() < t_go) __builtin_amdgcn_s_sleep(8);
+    }
+    int sidx = 0;
+    STAMP(sidx); ++sidx;
+    stage_a(0); stage_b(0); stage_b(1); stage_a(1);
+    s_advance();
+    stage_a(0); stage_b(0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    HMMC_BAR();
+    STAMP(sidx); ++sidx;
+    if (wm == 1) HMMC_BAR();
+    const int arow = wm * 64, brow = wn * 32;
+    while (true) {
+      const char* base = smem + buf * (4 * HALF);
+      h8 af[2][4], b0f[2][2], b1f[2][2];
+      // phase 1
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b0f[ks][j] = read_frag<BK, 128>(base + 2 * HALF, brow + j * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<AK, 128>(base, arow + i * 16, ks, lane);
+      stage_b(1);
+      HMMC_BAR();
+      HMMC_MM(0, 0, b0f);
+      HMMC_BAR();
+      // phase 2
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b1f[ks][j] = read_frag<BK, 128>(base + 3 * HALF, brow + j * 16, ks, lane);
+      stage_a(1);
+      s_advance();
+      HMMC_BAR();
+      HMMC_MM(0, 2, b1f);
+      HMMC_BAR();
+      // phase 3
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<AK, 128>(base + HALF, arow + i * 16, ks, lane);
+      stage_a(0);
+      HMMC_BAR();
+      HMMC_MM(4, 2, b1f);
+      HMMC_BAR();
+      // phase 4
+      stage_b(0);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      HMMC_BAR();
+      HMMC_MM(4, 0, b0f);
+      HMMC_BAR();
+      int n_item, n_split, n_tm, n_tn, n_kt, n_end;
+      next_pos(n_item, n_split, n_tm, n_tn, n_kt, n_end);
+      if (kt + 1 >= kt_end) { STAMP(sidx); ++sidx; finish_item(); STAMP(sidx); ++sidx; }
+      if (n_item >= nitems) break;
+      item = n_item; split = n_split; tm = n_tm; tn = n_tn; kt = n_kt; kt_end = n_end;
+      buf ^= 1;
+    }
+    if (wm == 0) HMMC_BAR();
+#undef HMMC_BAR
+#undef HMMC_MM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing out-of-range DMA must land before the LDS is released
+  } else if constexpr (MT == 8 && NT == 4) {
     // ---- 256x256 tile, one workgroup per CU: the two waves of a SIMD must hide each other's load issue.
     // One barrier per K-tile; the K-tile is cut into 4 stages of 16 MFMAs (k-step x row half).  Each stage
     // first issues the LDS reads of the NEXT stage's fragments (and, in stages 0/1, the 4+4 LDS-DMA loads
@@ -441,21 +673,21 @@ TileCfg pick_cfg(int M, int N, int K, bool allow_split) {
   return c;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PP = false>
 void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stream) {
-  constexpr int SMEM = 2 * (BM + BN) * BKT * 2 + WM * WN * EPI_SCRATCH;
+  constexpr int SMEM = 2 * (BM + BN) * BKT * 2;
   dim3 block(64 * WM * WN);
   if (SMEM > 64 * 1024) {
-    static bool once = (hmmc_allow_lds((const void*)gemm_f16_kernel<true, true, BM, BN, WM, WN>, SMEM),
-                        hmmc_allow_lds((const void*)gemm_f16_kernel<true, false, BM, BN, WM, WN>, SMEM),
-                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, true, BM, BN, WM, WN>, SMEM),
-                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, false, BM, BN, WM, WN>, SMEM), true);
+    static bool once = (hmmc_allow_lds((const void*)gemm_f16_kernel<true, true, BM, BN, WM, WN, PP>, SMEM),
+                        hmmc_allow_lds((const void*)gemm_f16_kernel<true, false, BM, BN, WM, WN, PP>, SMEM),
+                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, true, BM, BN, WM, WN, PP>, SMEM),
+                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, false, BM, BN, WM, WN, PP>, SMEM), true);
     (void)once;
   }
-  if (ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<true, true, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
-  else if (ak && !bk) hipLaunchKernelGGL((gemm_f16_kernel<true, false, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
-  else if (!ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<false, true, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
-  else hipLaunchKernelGGL((gemm_f16_kernel<false, false, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
+  if (ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<true, true, BM, BN, WM, WN, PP>), grid, block, SMEM, stream, p);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_f16_kernel<true, false, BM, BN, WM, WN, PP>), grid, block, SMEM, stream, p);
+  else if (!ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<false, true, BM, BN, WM, WN, PP>), grid, block, SMEM, stream, p);
+  else hipLaunchKernelGGL((gemm_f16_kernel<false, false, BM, BN, WM, WN, PP>), grid, block, SMEM, stream, p);
 }
 
 }  // namespace
@@ -493,6 +725,12 @@ extern "C" int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seco
   g_prof.clear();
   return HMMC_OK;
 }
+
+#ifdef HMMC_GEMM_STAMPS
+extern "C" int hmmc_gemm_debug_stamps(void* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" size_t hmmc_gemm_f16_workspace(int M, int N, int K) {
   TileCfg c = pick_cfg(M, N, K, true);
@@ -540,6 +778,9 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
     return n > 0 ? n : 256;
   }();
   long resident = (long)num_cu * (cfg.bm == 256 ? 1 : 2);       // workgroups the LDS budget keeps resident
+#ifdef HMMC_GEMM_STAMPS
+  { const char* e = getenv("HMMC_GEMM_GRID"); if (e && atoi(e) > 0) resident = atoi(e); }
+#endif
   dim3 grid((unsigned)(items < resident ? items : resident));
   GemmProfRec rec{};
   if (g_prof_on) {
@@ -551,7 +792,16 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
     rec.layout = a_kmajor ? (b_kmajor ? 0 : 1) : 2;
     (void)hipEventRecord(rec.e0, stream);
   }
-  if (cfg.bm == 256) launch_cfg<256, 256, 2, 4>(p, a_kmajor, b_kmajor, grid, stream);
+  {
+    static const int sg = [] { const char* e = getenv("HMMC_STAG_GRP"); return e ? atoi(e) : 1; }();
+    static const int sn = [] { const char* e = getenv("HMMC_STAG_NPH"); return e ? atoi(e) : 16; }();
+    static const int su = [] { const char* e = getenv("HMMC_STAG_US"); return e ? atoi(e) : 0; }();     // span in us; <0: fraction of item time in %
+    p.stag_grp = sg > 0 ? sg : 1; p.stag_nph = sn > 0 ? sn : 1;
+    p.stag_ticks = su >= 0 ? su * 100 : (int)(-su * 0.01 * p.ktps * 1.6 * 100);
+  }
+  static const bool pingpong = [] { const char* e = getenv("HMMC_GEMM_PINGPONG"); return !e || e[0] != '0'; }();
+  if (cfg.bm == 256 && pingpong) launch_cfg<256, 256, 2, 4, true>(p, a_kmajor, b_kmajor, grid, stream);
+  else if (cfg.bm == 256) launch_cfg<256, 256, 2, 4>(p, a_kmajor, b_kmajor, grid, stream);
   else launch_cfg<128, 128, 2, 2>(p, a_kmajor, b_kmajor, grid, stream);
   if (splitk > 1) {
     size_t nb = ((size_t)M * N / 4 + 255) / 256;
