@@ -38,15 +38,7 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc;
   int flags, splitk, ktps;
   unsigned a_bytes, b_bytes;
-  int stag_grp, stag_nph, stag_ticks;     // start stagger: ((lid / grp) % nph) * ticks / nph  (100 MHz ticks)
 };
-
-#ifdef HMMC_GEMM_STAMPS
-__device__ unsigned long long g_stamps[8][2][64];
-#define STAMP(IDX) do { if (bid < 8 && (wid & 3) == 0 && lane == 0 && (IDX) < 64) g_stamps[bid][wid >> 2][IDX] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define STAMP(IDX) do {} while (0)
-#endif
 
 // ---- LDS-DMA staging -------------------------------------------------------------------------
 // k-major tile image: [128 rows][8 chunks of 16 B]; phys chunk = logical ^ ((row >> 1) & 7)
@@ -312,7 +304,7 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, f4 (&acc)[MT][N
 // Persistent: the grid is sized to the chip and every workgroup walks work items (output tile x K-split)
 // item, item + gridDim, ...  The LDS-DMA prefetch runs one K-tile ahead across item boundaries, so the
 // first tile of the next output tile is already in flight while this one's epilogue stores drain.
-template <bool AK, bool BK, int BM, int BN, int WM, int WN, bool PP = false>
+template <bool AK, bool BK, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NTH = 64 * WM * WN;
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
@@ -343,9 +335,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int LOADS = (BM + BN) * 8 / NTH;   // LDS-DMA instructions per thread per K-tile
-  static_assert(NT == 4, "the staged epilogue assumes 64 columns per wave");
-  static_assert(LOADS == 8, "the counted vmcnt below assumes 8 loads per thread per tile");
+  static_assert(NT == 4, "the epilogue assumes 64 columns per wave");
+  static_assert((BM + BN) * 8 / NTH == 8, "the counted vmcnt below assumes 8 LDS-DMA loads per thread per K-tile");
 
   // current position (item, kt) and the decoded tile of the item
   int item = lid;
@@ -354,7 +345,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
   int tm = tile / ntn, tn = tile - tm * ntn;
   int kt = split * p.ktps, kt_end = min(nkt, kt + p.ktps);     // host guarantees kt < kt_end for every item
   int buf = 0;
-  if constexpr (!PP) {
+  if constexpr (MT != 8) {
     stage_tile<AK, BM, NTH>(ra, smem, wid, tid, tm * BM, kt * BKT, p.lda);
     stage_tile<BK, BN, NTH>(rb, smem + A_BYTES, wid, tid, tn * BN, kt * BKT, p.ldb);
   }
@@ -371,24 +362,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
       }
     }
   };
-  // VMEM stores this thread left in flight after an epilogue (0 = unknown / ragged tile: drain everything)
-  int pending_stores = 0;
+  // writes the finished tile and clears the accumulators for the next item (a zero C operand on the first K-tile
+  // instead of the clear measured 1-5 % slower: it doubles the MFMA blocks of the main loop)
   auto finish_item = [&]() {
-    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
-    if (p.splitk > 1) {
-      pending_stores = full ? MT * NT : 0;
+    if (p.splitk > 1)
       epilogue_slab<MT, NT>(p, acc, tm * BM + wm * (MT * 16) + (lane & 15), tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
-    } else {
-      pending_stores = !full ? 0 : (((p.flags & EPI_QGELU) && p.aux_out) ? 4 * MT : 2 * MT);
+    else
       epilogue_f16<MT>(p, acc, tm * BM + wm * (MT * 16), tn * BN + wn * (NT * 16), lane);
-    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
   };
 
-  if constexpr (MT == 8 && NT == 4 && PP) {
+  if constexpr (MT == 8 && NT == 4) {
     // ---- 256x256 tile, ping-pong schedule.  The two waves of a SIMD are wid and wid + 4, i.e. the wm = 0 and wm = 1
     // waves of one wn.  A K-tile is 4 phases of 16 MFMAs (one 64x32 quadrant x K = 64); each phase is a LOAD segment
     // (LDS fragment reads for this phase + the LDS-DMA of one half-tile of a later K-tile), a barrier, a MATRIX
@@ -438,19 +425,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
       acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[ks][j], af[ks][i], acc[I0 + i][J0 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0); } while (0)
-    if (p.stag_ticks > 0) {
-      const unsigned long long t_go = __builtin_amdgcn_s_memrealtime() +
-                                      (unsigned long long)(((lid / p.stag_grp) % p.stag_nph) * p.stag_ticks / p.stag_nph);
-      while (__builtin_amdgcn_s_memrealtime() < t_go) __builtin_amdgcn_s_sleep(8);
-    }
-    int sidx = 0;
-    STAMP(sidx); ++sidx;
     stage_a(0); stage_b(0); stage_b(1); stage_a(1);
     s_advance();
     stage_a(0); stage_b(0);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     HMMC_BAR();
-    STAMP(sidx); ++sidx;
     if (wm == 1) HMMC_BAR();
     const int arow = wm * 64, brow = wn * 32;
     while (true) {
@@ -496,7 +475,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
       HMMC_BAR();
       int n_item, n_split, n_tm, n_tn, n_kt, n_end;
       next_pos(n_item, n_split, n_tm, n_tn, n_kt, n_end);
-      if (kt + 1 >= kt_end) { STAMP(sidx); ++sidx; finish_item(); STAMP(sidx); ++sidx; }
+      if (kt + 1 >= kt_end) finish_item();
       if (n_item >= nitems) break;
       item = n_item; split = n_split; tm = n_tm; tn = n_tn; kt = n_kt; kt_end = n_end;
       buf ^= 1;
@@ -505,81 +484,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
 #undef HMMC_BAR
 #undef HMMC_MM
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing out-of-range DMA must land before the LDS is released
-  } else if constexpr (MT == 8 && NT == 4) {
-    // ---- 256x256 tile, one workgroup per CU: the two waves of a SIMD must hide each other's load issue.
-    // One barrier per K-tile; the K-tile is cut into 4 stages of 16 MFMAs (k-step x row half).  Each stage
-    // first issues the LDS reads of the NEXT stage's fragments (and, in stages 0/1, the 4+4 LDS-DMA loads
-    // of the next K-tile into the other buffer), then runs its MFMA cluster on fragments already in
-    // registers.  The other buffer is free as soon as the top barrier is passed (every wave has finished
-    // the previous K-tile), so no second barrier is needed.
-    while (true) {
-      int n_item, n_split, n_tm, n_tn, n_kt, n_end;
-      next_pos(n_item, n_split, n_tm, n_tn, n_kt, n_end);
-      const bool has_next = n_item < nitems;
-      // This K-tile's LDS-DMA loads are OLDER than the previous item's epilogue stores, and vmcnt retires in
-      // issue order: a counted wait lets those stores keep draining under this tile's MFMAs.
-      if (pending_stores == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-      else if (pending_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      pending_stores = 0;
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const char* sa = smem + buf * STAGE_BYTES;
-      const char* sb = sa + A_BYTES;
-      char* na = smem + (buf ^ 1) * STAGE_BYTES;
-      const int arow = wm * 128, brow = wn * 64;
-      h8 bc[4], bn[4], ac[4], an[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bc[j] = read_frag<BK, BN>(sb, brow + j * 16, 0, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ac[i] = read_frag<AK, BM>(sa, arow + i * 16, 0, lane);
-      // stage 0: k-step 0, rows 0-63
-#pragma unroll
-      for (int i = 0; i < 4; ++i) an[i] = read_frag<AK, BM>(sa, arow + (4 + i) * 16, 0, lane);
-      if (has_next) stage_tile<AK, BM, NTH>(ra, na, wid, tid, n_tm * BM, n_kt * BKT, p.lda);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[j], ac[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      // stage 1: k-step 0, rows 64-127
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ac[i] = read_frag<AK, BM>(sa, arow + i * 16, 1, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bn[j] = read_frag<BK, BN>(sb, brow + j * 16, 1, lane);
-      if (has_next) stage_tile<BK, BN, NTH>(rb, na + A_BYTES, wid, tid, n_tn * BN, n_kt * BKT, p.ldb);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[j], an[i], acc[4 + i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      // stage 2: k-step 1, rows 0-63
-#pragma unroll
-      for (int i = 0; i < 4; ++i) an[i] = read_frag<AK, BM>(sa, arow + (4 + i) * 16, 1, lane);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[j], ac[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      // stage 3: k-step 1, rows 64-127
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bn[j], an[i], acc[4 + i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 >= kt_end) finish_item();
-      if (!has_next) break;
-      item = n_item; split = n_split; tm = n_tm; tn = n_tn; kt = n_kt; kt_end = n_end;
-      buf ^= 1;
-    }
   } else {
     // ---- 128x128 tile, two workgroups per CU overlap each other: simple two-barrier loop
     while (true) {
@@ -673,21 +577,21 @@ TileCfg pick_cfg(int M, int N, int K, bool allow_split) {
   return c;
 }
 
-template <int BM, int BN, int WM, int WN, bool PP = false>
+template <int BM, int BN, int WM, int WN>
 void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stream) {
   constexpr int SMEM = 2 * (BM + BN) * BKT * 2;
   dim3 block(64 * WM * WN);
   if (SMEM > 64 * 1024) {
-    static bool once = (hmmc_allow_lds((const void*)gemm_f16_kernel<true, true, BM, BN, WM, WN, PP>, SMEM),
-                        hmmc_allow_lds((const void*)gemm_f16_kernel<true, false, BM, BN, WM, WN, PP>, SMEM),
-                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, true, BM, BN, WM, WN, PP>, SMEM),
-                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, false, BM, BN, WM, WN, PP>, SMEM), true);
+    static bool once = (hmmc_allow_lds((const void*)gemm_f16_kernel<true, true, BM, BN, WM, WN>, SMEM),
+                        hmmc_allow_lds((const void*)gemm_f16_kernel<true, false, BM, BN, WM, WN>, SMEM),
+                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, true, BM, BN, WM, WN>, SMEM),
+                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, false, BM, BN, WM, WN>, SMEM), true);
     (void)once;
   }
-  if (ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<true, true, BM, BN, WM, WN, PP>), grid, block, SMEM, stream, p);
-  else if (ak && !bk) hipLaunchKernelGGL((gemm_f16_kernel<true, false, BM, BN, WM, WN, PP>), grid, block, SMEM, stream, p);
-  else if (!ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<false, true, BM, BN, WM, WN, PP>), grid, block, SMEM, stream, p);
-  else hipLaunchKernelGGL((gemm_f16_kernel<false, false, BM, BN, WM, WN, PP>), grid, block, SMEM, stream, p);
+  if (ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<true, true, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_f16_kernel<true, false, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
+  else if (!ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<false, true, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
+  else hipLaunchKernelGGL((gemm_f16_kernel<false, false, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
 }
 
 }  // namespace
@@ -725,12 +629,6 @@ extern "C" int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seco
   g_prof.clear();
   return HMMC_OK;
 }
-
-#ifdef HMMC_GEMM_STAMPS
-extern "C" int hmmc_gemm_debug_stamps(void* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
-}
-#endif
 
 extern "C" size_t hmmc_gemm_f16_workspace(int M, int N, int K) {
   TileCfg c = pick_cfg(M, N, K, true);
@@ -778,9 +676,6 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
     return n > 0 ? n : 256;
   }();
   long resident = (long)num_cu * (cfg.bm == 256 ? 1 : 2);       // workgroups the LDS budget keeps resident
-#ifdef HMMC_GEMM_STAMPS
-  { const char* e = getenv("HMMC_GEMM_GRID"); if (e && atoi(e) > 0) resident = atoi(e); }
-#endif
   dim3 grid((unsigned)(items < resident ? items : resident));
   GemmProfRec rec{};
   if (g_prof_on) {
@@ -792,16 +687,7 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
     rec.layout = a_kmajor ? (b_kmajor ? 0 : 1) : 2;
     (void)hipEventRecord(rec.e0, stream);
   }
-  {
-    static const int sg = [] { const char* e = getenv("HMMC_STAG_GRP"); return e ? atoi(e) : 1; }();
-    static const int sn = [] { const char* e = getenv("HMMC_STAG_NPH"); return e ? atoi(e) : 16; }();
-    static const int su = [] { const char* e = getenv("HMMC_STAG_US"); return e ? atoi(e) : 0; }();     // span in us; <0: fraction of item time in %
-    p.stag_grp = sg > 0 ? sg : 1; p.stag_nph = sn > 0 ? sn : 1;
-    p.stag_ticks = su >= 0 ? su * 100 : (int)(-su * 0.01 * p.ktps * 1.6 * 100);
-  }
-  static const bool pingpong = [] { const char* e = getenv("HMMC_GEMM_PINGPONG"); return !e || e[0] != '0'; }();
-  if (cfg.bm == 256 && pingpong) launch_cfg<256, 256, 2, 4, true>(p, a_kmajor, b_kmajor, grid, stream);
-  else if (cfg.bm == 256) launch_cfg<256, 256, 2, 4>(p, a_kmajor, b_kmajor, grid, stream);
+  if (cfg.bm == 256) launch_cfg<256, 256, 2, 4>(p, a_kmajor, b_kmajor, grid, stream);
   else launch_cfg<128, 128, 2, 2>(p, a_kmajor, b_kmajor, grid, stream);
   if (splitk > 1) {
     size_t nb = ((size_t)M * N / 4 + 255) / 256;

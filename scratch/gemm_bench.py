@@ -1,6 +1,9 @@
 """GEMM microbenchmark at the tower shapes with the towers' epilogues (random data). usage: python scratch/gemm_bench.py [reps]"""
 import sys, time, torch
 sys.path.insert(0, '/root/repo')
+import os
+from hmmc_amd import _lib
+if os.environ.get('HMMC_LIB'): _lib.LIB_PATH = os.environ['HMMC_LIB']
 from hmmc_amd import ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 T = 153600

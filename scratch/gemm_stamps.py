@@ -23,3 +23,5 @@ for N, K in ((3072, 768),):
             t0 = t[0]
             rel = (t[:14] - t0) / 100.0
             print(f"  blk{blk} grp{w}: " + " ".join(f"{x:7.2f}" for x in rel))
+            ph = t[32:48]
+            print(f"      phase cycles (after each barrier, 2 K-tiles): " + " ".join(f"{int(x):5d}" for x in (ph[1:] - ph[:-1])))

@@ -2,6 +2,9 @@
 usage: python scratch/gemm_sweep.py [reps]"""
 import sys, torch
 sys.path.insert(0, '/root/repo')
+import os
+from hmmc_amd import _lib
+if os.environ.get('HMMC_LIB'): _lib.LIB_PATH = os.environ['HMMC_LIB']
 from hmmc_amd import ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 M = 65536
