@@ -18,8 +18,50 @@
 namespace {
 
 
+__device__ __forceinline__ h8 gfrag_clamped(const half_t* src, int row0, int ks, int L, long ld, int lane) {
+  int row = min(row0 + (lane & 15), L - 1);
+  return *reinterpret_cast<const h8*>(src + (long)row * ld + ks * 32 + 8 * (lane >> 4));
+}
+
+// store the wave's [LP][64] operand (row fragments in registers) into its LDS tile, row-major
 template <int KT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__device__ __forceinline__ void frags_to_tile(half_t* tile, const h8 (&f)[KT][2], int lane) {
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      *reinterpret_cast<h8*>(tile + (t * 16 + (lane & 15)) * LDS_STRIDE + ks * 32 + 8 * (lane >> 4)) = f[t][ks];
+}
+
+// X^T[d-tile dt][d = dt*16 + 4g + r][row = 16j + c] accumulators (4 d-tiles) -> global [row][64], 16 B per lane
+template <int KT>
+__device__ __forceinline__ void store_t(half_t* dst, long ld, const f4 (&acc)[4], int row, bool ok, int lane) {
+  const int g = lane >> 4;
+  unsigned d[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    h4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (half_t)acc[dt][r];
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v u = __builtin_bit_cast(u2v, v);
+    d[dt][0] = u[0]; d[dt][1] = u[1];
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      auto r = __builtin_amdgcn_permlane16_swap(d[2 * q][e], d[2 * q + 1][e], false, false);
+      d[2 * q][e] = r[0]; d[2 * q + 1][e] = r[1];
+    }
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    u4v o = {d[2 * q][0], d[2 * q][1], d[2 * q + 1][0], d[2 * q + 1][1]};
+    if (ok) *reinterpret_cast<u4v*>(dst + (long)row * ld + 32 * q + 16 * (g & 1) + 8 * (g >> 1)) = o;
+  }
+}
+
+template <int KT>
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
   constexpr int LP = 16 * KT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -32,41 +74,50 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   const half_t* q = p.qkv + (long)n * L * ld + h * DH;
   const half_t* k = q + D;
   const half_t* v = q + 2 * D;
-  half_t* ktile = reinterpret_cast<half_t*>(smem) + wid * (2 * LP * LDS_STRIDE);
-  half_t* vtile = ktile + LP * LDS_STRIDE;
-  load_tile<LP>(ktile, k, L, ld, lane);
-  load_tile<LP>(vtile, v, L, ld, lane);
-
+  half_t* vtile = reinterpret_cast<half_t*>(smem) + wid * (LP * LDS_STRIDE);
   const int g = lane >> 4, c = lane & 15;
-  // S^T[key][q] = sum_d K[key][d] Q[q][d]
-  f4 s[KT][KT];
+
+  // every operand is requested before the first MFMA (rows past L clamped; masked below where it matters)
+  h8 kf[KT][2], qf[KT][2], vf[KT][2];
 #pragma unroll
-  for (int qt = 0; qt < KT; ++qt) {
-    h8 qf0 = gfrag(q, qt * 16, 0, L, ld, lane), qf1 = gfrag(q, qt * 16, 1, L, ld, lane);
+  for (int t = 0; t < KT; ++t)
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      const half_t* kr = ktile + (kt * 16 + c) * LDS_STRIDE + 8 * g;
-      h8 kf0 = *reinterpret_cast<const h8*>(kr), kf1 = *reinterpret_cast<const h8*>(kr + 32);
-      f4 a = {0.f, 0.f, 0.f, 0.f};
-      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf0, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf1, a, 0, 0, 0);
-      s[kt][qt] = a;
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[t][ks] = gfrag_clamped(k, t * 16, ks, L, ld, lane);
+      qf[t][ks] = gfrag_clamped(q, t * 16, ks, L, ld, lane);
     }
-  }
-  // softmax over keys for query column (qt*16 + c); lane holds keys kt*16 + 4g + r
-  h4 pt[KT][KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) vf[t][ks] = gfrag_clamped(v, t * 16, ks, L, ld, lane);
+  frags_to_tile<KT>(vtile, vf, lane);
+  h8 vT[4][KT / 2];                              // V^T fragments, k-order permuted like the P^T accumulators
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int ks = 0; ks < KT / 2; ++ks) vT[dt][ks] = tr_frag(vtile, ks * 32, ks * 32 + 16, dt * 16, lane);
+
+  half_t* o = p.out + (long)n * L * D + h * DH;
 #pragma unroll
   for (int qt = 0; qt < KT; ++qt) {
     const int qi = qt * 16 + c;
+    // S^T[key][q] = sum_d K[key][d] Q[q][d]; lane holds keys kt*16 + 4g + r of query column qi
+    f4 s[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      f4 z = {0.f, 0.f, 0.f, 0.f};
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][0], qf[qt][0], z, 0, 0, 0);
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][1], qf[qt][1], s[kt], 0, 0, 0);
+    }
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int key = kt * 16 + 4 * g + r;
-        bool ok = key < L && (!p.causal || key <= qi || qi >= L);
-        float val = ok ? s[kt][qt][r] * 0.125f : -INFINITY;
-        s[kt][qt][r] = val;
+        const int key = kt * 16 + 4 * g + r;
+        float val = s[kt][r] * 0.125f;
+        if ((kt + 1) * 16 > L || p.causal) val = (key < L && (!p.causal || key <= qi || qi >= L)) ? val : -INFINITY;
+        s[kt][r] = val;
         m = fmaxf(m, val);
       }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -76,48 +127,49 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float e = __expf(s[kt][qt][r] - m);
-        s[kt][qt][r] = e;
+        float e = __expf(s[kt][r] - m);
+        s[kt][r] = e;
         sum += e;
       }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (p.lse && g == 0 && qi < L) p.lse[((long)n * p.H + h) * L + qi] = m + __logf(sum);
+    h4 pt[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pt[kt][qt][r] = (half_t)(s[kt][qt][r] * inv);
-  }
-  // O^T[d][q] = sum_key V[key][d] P[q][key]; k-step s covers key tiles 2s, 2s+1 in permuted order
-  half_t* o = p.out + (long)n * L * D + h * DH;
+      for (int r = 0; r < 4; ++r) pt[kt][r] = (half_t)(s[kt][r] * inv);
+    // O^T[d][q] = sum_key V[key][d] P[q][key]; k-step ks covers key tiles 2ks, 2ks+1 in permuted order
+    f4 acc[4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    h8 vf[KT / 2];
-#pragma unroll
-    for (int ks = 0; ks < KT / 2; ++ks) vf[ks] = tr_frag(vtile, ks * 32, ks * 32 + 16, dt * 16, lane);
-#pragma unroll
-    for (int qt = 0; qt < KT; ++qt) {
-      f4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < 4; ++dt) {
+      acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KT / 2; ++ks)
-        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[ks], cat4(pt[2 * ks][qt], pt[2 * ks + 1][qt]), a, 0, 0, 0);
-      int qi = qt * 16 + c;
-      if (qi < L) {
-        h4 ov;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (half_t)a[r];
-        *reinterpret_cast<h4*>(o + (long)qi * D + dt * 16 + 4 * g) = ov;
-      }
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vT[dt][ks], cat4(pt[2 * ks], pt[2 * ks + 1]), acc[dt], 0, 0, 0);
     }
+    store_t<KT>(o, D, acc, qi, qi < L, lane);
   }
 }
 
-// Backward.  One wave per (sequence, head); two LDS buffers per wave (tile X: K, then dO, then Q;
-// tile Y: P^T then dS^T, both stored [key][q]).
+// Backward.  One wave per (sequence, head), no workgroup barrier.
+//  * Every global operand (Q, K, V, dO row fragments: 8 x KT loads of 1 KiB per wave) is requested before the first
+//    MFMA, so a wave has its whole input in flight at once and the two waves of a SIMD cover each other's latency.
+//    Rows past L are clamped, never masked: their probabilities are forced to zero instead (lse = +inf for queries,
+//    an explicit key mask in the last key tile), so whatever they hold cannot reach an output.
+//  * softmax backward exactly as autograd writes it: dS = P o (dP - rowsum(P o dP)); the attention output O is not read.
+//  * S and dP are formed in BOTH orientations from the same register fragments (MFMA operands swapped): keys on the
+//    lane's rows for dQ (the accumulator tile is directly the B operand of dQ^T = K^T dS^T), queries on the lane's rows
+//    for dV^T = dO^T P and dK^T = Q^T dS.  That costs 2 x the (cheap) QK^T / dO V^T MFMAs and exponentials and
+//    removes every LDS transpose of P / dS.
+//  * One 9 KiB LDS tile per wave, refilled from registers (K, then dO, then Q), serves the three transposed
+//    operands (ds_read_b64_tr_b16); per-query lse / delta are redistributed through 512 B of scratch.
+//  * Outputs leave as 16 B per lane: v_permlane16_swap pairs the d-tiles (2q, 2q+1) so a lane owns 8 consecutive d.
 template <int KT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = 16 * KT;
+  constexpr int WAVE_LDS = LP * LDS_STRIDE * 2 + 2 * LP * 4;     // tile + lse[LP] + delta[LP]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -129,108 +181,135 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
   const half_t* q = p.qkv + (long)n * L * ld + h * DH;
   const half_t* k = q + D;
   const half_t* v = q + 2 * D;
-  const half_t* o = p.out + (long)n * L * D + h * DH;
   const half_t* dO = p.dout + (long)n * L * D + h * DH;
   half_t* dq = p.dqkv + (long)n * L * ld + h * DH;
   half_t* dk = dq + D;
   half_t* dv = dq + 2 * D;
-  half_t* xt = reinterpret_cast<half_t*>(smem) + wid * (2 * LP * LDS_STRIDE);
-  half_t* yt = xt + LP * LDS_STRIDE;
+  half_t* xt = reinterpret_cast<half_t*>(smem + wid * WAVE_LDS);
+  float* lse_s = reinterpret_cast<float*>(smem + wid * WAVE_LDS + LP * LDS_STRIDE * 2);
+  float* del_s = lse_s + LP;
   const int g = lane >> 4, c = lane & 15;
+  const float* lse_g = p.lse + ((long)n * p.H + h) * L;
 
-  load_tile<LP>(xt, k, L, ld, lane);   // X = K (needed transposed for dQ)
+  h8 qf[KT][2], kf[KT][2], vf[KT][2], df[KT][2];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[t][ks] = gfrag_clamped(k, t * 16, ks, L, ld, lane);
+      qf[t][ks] = gfrag_clamped(q, t * 16, ks, L, ld, lane);
+    }
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      vf[t][ks] = gfrag_clamped(v, t * 16, ks, L, ld, lane);
+      df[t][ks] = gfrag_clamped(dO, t * 16, ks, L, D, lane);
+    }
+  float lse_c[KT];                               // lse of query qt*16 + c; +inf past L: its probabilities vanish
+#pragma unroll
+  for (int t = 0; t < KT; ++t) lse_c[t] = (t * 16 + c < L) ? lse_g[t * 16 + c] : INFINITY;
+  if (g == 0) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) lse_s[t * 16 + c] = lse_c[t];
+  }
 
-  // phase A: P^T and dS^T in registers
-  h4 pt[KT][KT], dst[KT][KT];
+  // ---- phase 1: keys on the lane's rows -> delta and dQ
+  frags_to_tile<KT>(xt, kf, lane);
 #pragma unroll
   for (int qt = 0; qt < KT; ++qt) {
     const int qi = qt * 16 + c;
-    h8 qf0 = gfrag(q, qt * 16, 0, L, ld, lane), qf1 = gfrag(q, qt * 16, 1, L, ld, lane);
-    h8 df0 = gfrag(dO, qt * 16, 0, L, D, lane), df1 = gfrag(dO, qt * 16, 1, L, D, lane);
-    h8 of0 = gfrag(o, qt * 16, 0, L, D, lane), of1 = gfrag(o, qt * 16, 1, L, D, lane);
-    float delta = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) delta += (float)df0[j] * (float)of0[j] + (float)df1[j] * (float)of1[j];
-    delta += __shfl_xor(delta, 16, 64);
-    delta += __shfl_xor(delta, 32, 64);
-    const float lse = qi < L ? p.lse[((long)n * p.H + h) * L + qi] : 0.f;
+    f4 s[KT], dp[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      const half_t* kr = xt + (kt * 16 + c) * LDS_STRIDE + 8 * g;
-      h8 kf0 = *reinterpret_cast<const h8*>(kr), kf1 = *reinterpret_cast<const h8*>(kr + 32);
-      h8 vf0 = gfrag(v, kt * 16, 0, L, ld, lane), vf1 = gfrag(v, kt * 16, 1, L, ld, lane);
-      f4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-      s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf0, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf1, s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf0, df0, dp, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf1, df1, dp, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = kt * 16 + 4 * g + r;
-        bool ok = key < L && qi < L && (!p.causal || key <= qi);
-        float pv = ok ? __expf(s[r] * 0.125f - lse) : 0.f;
-        pt[kt][qt][r] = (half_t)pv;
-        dst[kt][qt][r] = (half_t)(pv * (dp[r] - delta) * 0.125f);
-      }
+      f4 z = {0.f, 0.f, 0.f, 0.f};
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][0], qf[qt][0], z, 0, 0, 0);
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][1], qf[qt][1], s[kt], 0, 0, 0);
+      dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[kt][0], df[qt][0], z, 0, 0, 0);
+      dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[kt][1], df[qt][1], dp[kt], 0, 0, 0);
     }
-  }
-  // dQ^T[d][q] = sum_key K[key][d] dS[q][key]   (K^T via transposed reads of X)
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    h8 kf[KT / 2];
-#pragma unroll
-    for (int ks = 0; ks < KT / 2; ++ks) kf[ks] = tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane);
-#pragma unroll
-    for (int qt = 0; qt < KT; ++qt) {
-      f4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KT / 2; ++ks)
-        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[ks], cat4(dst[2 * ks][qt], dst[2 * ks + 1][qt]), a, 0, 0, 0);
-      int qi = qt * 16 + c;
-      if (qi < L) {
-        h4 ov;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (half_t)a[r];
-        *reinterpret_cast<h4*>(dq + (long)qi * ld + dt * 16 + 4 * g) = ov;
-      }
-    }
-  }
-  // dV^T[d][key] = sum_q dO[q][d] P[q][key]: X = dO (transposed reads), Y = P^T as [key][q]
-  // dK^T[d][key] = sum_q Q[q][d] dS[q][key]: X = Q,                      Y = dS^T
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    load_tile<LP>(xt, pass == 0 ? dO : q, L, pass == 0 ? (long)D : ld, lane);
+    float dl = 0.f;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int qt = 0; qt < KT; ++qt)
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        float pv = __expf(s[kt][r] * 0.125f - lse_c[qt]);
+        if ((kt + 1) * 16 > L || p.causal) pv = (key < L && (!p.causal || key <= qi)) ? pv : 0.f;
+        s[kt][r] = pv;
+        dl += pv * dp[kt][r];
+      }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (g == 0) del_s[qi] = dl;
+    h4 ds16[KT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          yt[(kt * 16 + 4 * g + r) * LDS_STRIDE + qt * 16 + c] = pass == 0 ? pt[kt][qt][r] : dst[kt][qt][r];
-    half_t* dst_ptr = pass == 0 ? dv : dk;
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds16[kt][r] = (half_t)(s[kt][r] * (dp[kt][r] - dl) * 0.125f);
+    f4 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      h8 xf[KT / 2];
+      acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KT / 2; ++ks) xf[ks] = tr_frag(xt, ks * 32 + 4 * 0, ks * 32 + 16, dt * 16, lane);
+      for (int ks = 0; ks < KT / 2; ++ks)          // K^T fragments re-read from the tile: keeps 32 VGPRs free
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane),
+                                                         cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[dt], 0, 0, 0);
+    }
+    store_t<KT>(dq, ld, acc, qi, qi < L, lane);
+  }
+
+  // ---- phase 2a: queries on the lane's rows -> P and dS as B operands of dV / dK
+  h4 p16[KT][KT], ds16[KT][KT];                  // [kt][qt]
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        f4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < KT; ++kt) {
+    const int key = kt * 16 + c;
+    f4 s[KT], dp[KT];
+#pragma unroll
+    for (int qt = 0; qt < KT; ++qt) {
+      f4 z = {0.f, 0.f, 0.f, 0.f};
+      s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qt][0], kf[kt][0], z, 0, 0, 0);
+      s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qt][1], kf[kt][1], s[qt], 0, 0, 0);
+      dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[qt][0], vf[kt][0], z, 0, 0, 0);
+      dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[qt][1], vf[kt][1], dp[qt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int qt = 0; qt < KT; ++qt) {
+      const f4 lr = *reinterpret_cast<const f4*>(lse_s + qt * 16 + 4 * g);
+      const f4 dr = *reinterpret_cast<const f4*>(del_s + qt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = qt * 16 + 4 * g + r;
+        float pv = __expf(s[qt][r] * 0.125f - lr[r]);
+        if ((kt + 1) * 16 > L || p.causal) pv = (key < L && (!p.causal || key <= qi)) ? pv : 0.f;
+        p16[kt][qt][r] = (half_t)pv;
+        ds16[kt][qt][r] = (half_t)(pv * (dp[qt][r] - dr[r]) * 0.125f);
+      }
+    }
+  }
+  // ---- phase 2b: dV^T[d][key] = sum_q dO[q][d] P[q][key];  dK^T[d][key] = sum_q Q[q][d] dS[q][key]
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 0) frags_to_tile<KT>(xt, df, lane); else frags_to_tile<KT>(xt, qf, lane);
+    h8 xT[4][KT / 2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < KT / 2; ++ks) xT[dt][ks] = tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      f4 acc[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KT / 2; ++ks) {
-          // B fragment: Y[key = kt*16 + c][q in the same permuted order as tr_frag's rows]
-          const half_t* yr = yt + (kt * 16 + c) * LDS_STRIDE + ks * 32 + 4 * g;
-          h4 lo = *reinterpret_cast<const h4*>(yr), hi = *reinterpret_cast<const h4*>(yr + 16);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[ks], cat4(lo, hi), a, 0, 0, 0);
-        }
-        int key = kt * 16 + c;
-        if (key < L) {
-          h4 ov;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ov[r] = (half_t)a[r];
-          *reinterpret_cast<h4*>(dst_ptr + (long)key * ld + dt * 16 + 4 * g) = ov;
+          h8 bfrag = pass == 0 ? cat4(p16[kt][2 * ks], p16[kt][2 * ks + 1]) : cat4(ds16[kt][2 * ks], ds16[kt][2 * ks + 1]);
+          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xT[dt][ks], bfrag, acc[dt], 0, 0, 0);
         }
       }
+      const int key = kt * 16 + c;
+      store_t<KT>(pass == 0 ? dv : dk, ld, acc, key, key < L, lane);
     }
   }
 }
@@ -253,10 +332,8 @@ extern "C" int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, in
   p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = lse; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   long pairs = (long)nseq * H;
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
-  static bool once = (hmmc_allow_lds((const void*)attn_fwd_kernel<4>, 4 * 2 * 64 * LDS_STRIDE * 2), true);
-  (void)once;
-  if (L <= 32) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, 4 * 2 * 32 * LDS_STRIDE * 2, stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, 4 * 2 * 64 * LDS_STRIDE * 2, stream, p);
+  if (L <= 32) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, 4 * 32 * LDS_STRIDE * 2, stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, 4 * 64 * LDS_STRIDE * 2, stream, p);
   return hmmc_launch_status();
 }
 
@@ -275,9 +352,7 @@ extern "C" int hmmc_attention_f16_bwd(const void* qkv, const void* out, const fl
   p.dqkv = (half_t*)dqkv; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   long pairs = (long)nseq * H;
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
-  static bool once = (hmmc_allow_lds((const void*)attn_bwd_kernel<4>, 4 * 2 * 64 * LDS_STRIDE * 2), true);
-  (void)once;
-  if (L <= 32) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, 4 * 2 * 32 * LDS_STRIDE * 2, stream, p);
-  else hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, block, 4 * 2 * 64 * LDS_STRIDE * 2, stream, p);
+  if (L <= 32) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, 4 * (32 * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);
+  else hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, block, 4 * (64 * LDS_STRIDE * 2 + 2 * 64 * 4), stream, p);
   return hmmc_launch_status();
 }
