@@ -18,12 +18,13 @@ _C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c
 # name -> (argument codes, return code); must match include/hmmc_hip.h
 SIGNATURES = {
     "hmmc_gemm_f16_workspace": ("iii", "z"),
+    "hmmc_gemm_f16_colsum_rows": ("iii", "z"),
     "hmmc_gemm_f16": ("pppiiiiiiiippppipzp", "i"),
     "hmmc_gemm_profile_start": ("", "i"),
     "hmmc_gemm_profile_stop": ("pppp", "i"),
     "hmmc_layernorm_fwd": ("pppppppiilfip", "i"),
     "hmmc_layernorm_bwd_workspace": ("ii", "z"),
-    "hmmc_layernorm_bwd": ("ppppppppppiilipzp", "i"),
+    "hmmc_layernorm_bwd": ("pppppppppppiilipzp", "i"),
     "hmmc_colsum_workspace": ("ii", "z"),
     "hmmc_colsum": ("ppiiliiipzp", "i"),
     "hmmc_patchify": ("ppiiiip", "i"),
@@ -32,7 +33,7 @@ SIGNATURES = {
     "hmmc_text_embed_bwd": ("ppplip", "i"),
     "hmmc_cast": ("pplip", "i"),
     "hmmc_attention_f16_fwd": ("pppiiiip", "i"),
-    "hmmc_attention_f16_bwd": ("pppppiiiip", "i"),
+    "hmmc_attention_f16_bwd": ("ppppppiiiip", "i"),
     "hmmc_gemm_f32": ("pppiiillllifppppip", "i"),
     "hmmc_l2norm_fwd": ("pppiifp", "i"),
     "hmmc_l2norm_bwd": ("ppppiip", "i"),
@@ -65,7 +66,7 @@ SIGNATURES = {
     "hmmc_ce_bwd": ("pppppilp", "i"),
     "hmmc_tower_act_bytes": ("liiiii", "z"),
     "hmmc_tower_bwd_scratch_bytes": ("lii", "z"),
-    "hmmc_tower_workspace_bytes": ("lii", "z"),
+    "hmmc_tower_workspace_bytes": ("liii", "z"),
     "hmmc_tower_fwd": ("ppppiiiiiiifipzp", "i"),
     "hmmc_tower_bwd": ("pppppppiiiiiiipzp", "i"),
 }

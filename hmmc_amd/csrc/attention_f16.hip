@@ -166,6 +166,32 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 //  * One 9 KiB LDS tile per wave, refilled from registers (K, then dO, then Q), serves the three transposed
 //    operands (ds_read_b64_tr_b16); per-query lse / delta are redistributed through 512 B of scratch.
 //  * Outputs leave as 16 B per lane: v_permlane16_swap pairs the d-tiles (2q, 2q+1) so a lane owns 8 consecutive d.
+// column sums over the 16 lanes c of a 16-lane row (every lane ends with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+// csum[dt][r] += the fp16-rounded value of acc[dt][r] (what the stored tensor holds)
+__device__ __forceinline__ void add_rounded(f4 (&csum)[4], const f4 (&acc)[4]) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) csum[dt][r] += (float)(half_t)acc[dt][r];
+}
+// dst[dt*16 + 4g + r] = sum over the 16 lanes c of csum[dt][r]
+__device__ __forceinline__ void store_colsum(float* dst, f4 (&csum)[4], int lane) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    f4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = row16_sum(csum[dt][r]);
+    if ((lane & 15) == 0) *reinterpret_cast<f4*>(dst + dt * 16 + 4 * (lane >> 4)) = t;
+  }
+}
+
 template <int KT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = 16 * KT;
@@ -214,8 +240,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
     for (int t = 0; t < KT; ++t) lse_s[t * 16 + c] = lse_c[t];
   }
 
+  float* dbias = p.dbias ? p.dbias + (long)n * 3 * D + h * DH : nullptr;   // + type * D
+  f4 csum[4];
   // ---- phase 1: keys on the lane's rows -> delta and dQ
   frags_to_tile<KT>(xt, kf, lane);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) csum[dt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int qt = 0; qt < KT; ++qt) {
     const int qi = qt * 16 + c;
@@ -257,7 +287,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
                                                          cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[dt], 0, 0, 0);
     }
     store_t<KT>(dq, ld, acc, qi, qi < L, lane);
+    if (dbias) add_rounded(csum, acc);           // rows past L are exact zeros (their dS is)
   }
+  if (dbias) store_colsum(dbias, csum, lane);
 
   // ---- phase 2a: queries on the lane's rows -> P and dS as B operands of dV / dK
   h4 p16[KT][KT], ds16[KT][KT];                  // [kt][qt]
@@ -291,6 +323,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 0) frags_to_tile<KT>(xt, df, lane); else frags_to_tile<KT>(xt, qf, lane);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) csum[dt] = f4{0.f, 0.f, 0.f, 0.f};
     h8 xT[4][KT / 2];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -310,7 +344,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
       }
       const int key = kt * 16 + c;
       store_t<KT>(pass == 0 ? dv : dk, ld, acc, key, key < L, lane);
+      if (dbias) add_rounded(csum, acc);         // keys past L are exact zeros (P and dS are)
     }
+    if (dbias) store_colsum(dbias + (pass == 0 ? 2 : 1) * D, csum, lane);
   }
 }
 
@@ -338,18 +374,19 @@ extern "C" int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, in
 }
 
 extern "C" int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
-                                      int nseq, int L, int H, int causal, hipStream_t stream) {
+                                      float* dbias_partial, int nseq, int L, int H, int causal, hipStream_t stream) {
   if (!qkv || !out || !lse || !dout || !dqkv || nseq <= 0 || L <= 0 || H <= 0) return HMMC_ERR_ARG;
   if (L > 256) return HMMC_ERR_UNSUPPORTED;
   if (L > 64) {
     AttnArgs pl{};
     pl.qkv = (const half_t*)qkv; pl.out = (half_t*)out; pl.lse = (float*)lse; pl.dout = (const half_t*)dout;
     pl.dqkv = (half_t*)dqkv; pl.nseq = nseq; pl.L = L; pl.H = H; pl.causal = causal;
+    if (dbias_partial) return HMMC_ERR_UNSUPPORTED;      // the long-sequence kernel has no fused bias partials
     return hmmc_attention_long_bwd(pl, stream);
   }
   AttnArgs p{};
   p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = (float*)lse; p.dout = (const half_t*)dout;
-  p.dqkv = (half_t*)dqkv; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
+  p.dqkv = (half_t*)dqkv; p.dbias = dbias_partial; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   long pairs = (long)nseq * H;
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
   if (L <= 32) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, 4 * (32 * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);

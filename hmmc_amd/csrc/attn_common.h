@@ -6,6 +6,7 @@
 struct HmmcAttnArgs {
   const half_t* qkv; half_t* out; float* lse;
   const half_t* dout; half_t* dqkv;
+  float* dbias;                 // optional [nseq][3D]: per-sequence column sums of dqkv (in_proj bias gradient partials)
   int nseq, L, H, causal;
 };
 typedef HmmcAttnArgs AttnArgs;

@@ -29,12 +29,13 @@ namespace {
 
 constexpr int BKT = 64;
 
-enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8 };
+enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32 };
 
 struct GemmArgs {
   const half_t* A; const half_t* B; half_t* C;
   const half_t* bias; const half_t* resid; half_t* aux_out; const half_t* aux_in;
   float* ws;
+  float* csum;                  // EPI_COLSUM: fp32 [row blocks of 128 (256x256 tile) or 64 rows][N] partial column sums of C
   int M, N, K, lda, ldb, ldc;
   int flags, splitk, ktps;
   unsigned a_bytes, b_bytes;
@@ -176,7 +177,7 @@ __device__ __forceinline__ void to_store_order(u4& x, u4& y) {
 // F >= 0: the epilogue flags at compile time; F < 0: p.flags at run time
 template <int MT, int F>
 __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
-  const int flags = F >= 0 ? F : p.flags;
+  const int flags = F >= 0 ? F : (p.flags & ~EPI_COLSUM);
   const int c = lane & 15, g = lane >> 4;
   const int n_l = 32 * (c >> 3) + 16 * (g & 1) + 8 * (g >> 1);   // this lane's 8 columns within the wave's 64
   const bool n_ok = n0 + n_l < p.N;                              // N % 8 == 0: a 16-byte piece is all-in or all-out
@@ -198,6 +199,9 @@ __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4
   constexpr int HB = MT > 4 ? 4 : MT;            // strips whose operand loads are in flight together (32 VGPRs)
   u4 rin[HB][2];
   const bool two = (flags & EPI_QGELU) && p.aux_out;
+  f4 csum[4];                                    // EPI_COLSUM: column sums of the fp16 values written, over this wave's rows
+#pragma unroll
+  for (int j = 0; j < 4; ++j) csum[j] = f4{0.f, 0.f, 0.f, 0.f};
   auto store2 = [&](half_t* dst, int i, u4 o0, u4 o1) {
     char* sb = reinterpret_cast<char*>(dst) + ((size_t)(m_base + 16 * i) * p.ldc + n0) * 2u;
     if (full) {
@@ -257,6 +261,13 @@ __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4
         for (int r = 0; r < 4; ++r) out[j][r] = (half_t)v[r];
       }
     }
+    if (p.csum) {
+      const bool row_ok = m_base + 16 * i + c < p.M;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) csum[j][r] += row_ok ? (float)out[j][r] : 0.f;
+    }
     {
       u4 o0 = join(out[0], out[1]), o1 = join(out[2], out[3]);
       swap_pair(o0); swap_pair(o1);
@@ -270,11 +281,29 @@ __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4
       store2(p.aux_out, i, o0, o1);
     }
   }
+  if (p.csum) {                                  // 16 lanes c -> one partial row per wave: row block (m_base / (16 MT))
+    float* dst = p.csum + (size_t)(m_base / (16 * MT)) * p.N + n0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f4 t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = csum[j][r];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+        t[r] = v;
+      }
+      const int n = n0 + 16 * j + 4 * g;
+      if (c == 0 && n < p.N) *reinterpret_cast<f4*>(dst + 16 * j + 4 * g) = t;
+    }
+  }
 }
 
 template <int MT>
 __device__ __forceinline__ void epilogue_f16(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
-  switch (p.flags) {                            // the combinations the towers use get straight-line code
+  switch (p.flags & ~EPI_COLSUM) {              // the combinations the towers use get straight-line code
     case 0: epilogue_impl<MT, 0>(p, acc, m_base, n0, lane); break;
     case EPI_BIAS: epilogue_impl<MT, EPI_BIAS>(p, acc, m_base, n0, lane); break;
     case EPI_BIAS | EPI_RESID: epilogue_impl<MT, EPI_BIAS | EPI_RESID>(p, acc, m_base, n0, lane); break;
@@ -630,6 +659,12 @@ extern "C" int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seco
   return HMMC_OK;
 }
 
+// rows of the fp32 [rows][N] partial matrix an EPI_COLSUM launch writes into `workspace`
+extern "C" size_t hmmc_gemm_f16_colsum_rows(int M, int N, int K) {
+  TileCfg c = pick_cfg(M, N, K, false);
+  return (size_t)((M + c.bm - 1) / c.bm) * 2;   // two wave rows per tile in both configurations
+}
+
 extern "C" size_t hmmc_gemm_f16_workspace(int M, int N, int K) {
   TileCfg c = pick_cfg(M, N, K, true);
   return c.splitk > 1 ? (size_t)c.splitk * M * N * sizeof(float) : 0;
@@ -662,6 +697,11 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
   p.a_bytes = (unsigned)a_bytes; p.b_bytes = (unsigned)b_bytes;
   int nkt = (K + BKT - 1) / BKT;
   TileCfg cfg = pick_cfg(M, N, K, epilogue == 0);
+  p.csum = nullptr;
+  if (epilogue & EPI_COLSUM) {
+    if ((N & 3) || !workspace || ws_bytes < hmmc_gemm_f16_colsum_rows(M, N, K) * N * sizeof(float)) return HMMC_ERR_WORKSPACE;
+    p.csum = (float*)workspace;
+  }
   int splitk = cfg.splitk;
   if (splitk > 1 && (!workspace || ws_bytes < (size_t)splitk * M * N * sizeof(float))) splitk = 1;
   p.ktps = (nkt + splitk - 1) / splitk;

@@ -80,18 +80,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd_in, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ partial,
                                                      const int* __restrict__ row_index, int rows, int D,
-                                                     long in_stride) {
+                                                     long in_stride, int want_dxsum) {
   constexpr int VN = Vec<T>::N;
   constexpr int LN_MAXV = LN_MAXD / 64 / VN;
   typedef typename Vec<T>::type V;
   __shared__ float sred[4 * LN_MAXD];   // one stripe per wave
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nchunk = D / VN;
-  float dg[LN_MAXV][VN], db[LN_MAXV][VN];
-#pragma unroll
+  float dg[LN_MAXV][VN], db[LN_MAXV][VN], ds[LN_MAXV][VN];   // ds: column sums of the dx rows written (bias gradient
+#pragma unroll                                                //     of the linear layer that produced this activation)
   for (int i = 0; i < LN_MAXV; ++i)
 #pragma unroll
-    for (int j = 0; j < VN; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+    for (int j = 0; j < VN; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; ds[i][j] = 0.f; }
 
   for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
     const long src_row = row_index ? (long)row_index[row] : (long)row;
@@ -134,26 +134,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
           float val = rstd * (g[i][j] - s1 - xh[i][j] * s2);
           if (drr) val += (float)rr[j];
           o[j] = (T)val;
+          ds[i][j] += (float)o[j];
         }
         *reinterpret_cast<V*>(dxr + c * VN) = o;
       }
     }
   }
-  // combine the 4 waves of the block, then one partial row per block: partial[block][0|1][D]
-  for (int pass = 0; pass < 2; ++pass) {
+  // combine the 4 waves of the block, then one partial row per block: partial[block][0|1|2][D]
+  const int npass = want_dxsum ? 3 : 2;
+  for (int pass = 0; pass < npass; ++pass) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       int c = lane + 64 * i;
       if (c < nchunk) {
 #pragma unroll
-        for (int j = 0; j < VN; ++j) sred[w * LN_MAXD + c * VN + j] = pass ? db[i][j] : dg[i][j];
+        for (int j = 0; j < VN; ++j) sred[w * LN_MAXD + c * VN + j] = pass == 0 ? dg[i][j] : (pass == 1 ? db[i][j] : ds[i][j]);
       }
     }
     __syncthreads();
     for (int col = threadIdx.x; col < D; col += 256) {
       float t = sred[col] + sred[LN_MAXD + col] + sred[2 * LN_MAXD + col] + sred[3 * LN_MAXD + col];
-      partial[((long)blockIdx.x * 2 + pass) * D + col] = t;
+      partial[((long)blockIdx.x * npass + pass) * D + col] = t;
     }
   }
 }
@@ -185,6 +187,35 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     if (round_f16) t = r16(t);
     if (col < split) out0[col] = (TO)t;
     else out1[col - split] = (TO)t;
+  }
+}
+
+// LayerNorm backward second stage: columns [0,D) -> dgamma, [D,2D) -> dbeta (fp32), [2D,3D) -> dx_colsum (fp16 or fp32)
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, void* __restrict__ dxsum, int dx_dtype,
+                                                        int R, int N, int D) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < N) {
+    int r = rl;
+    for (; r + 8 < R; r += 16) {
+      a0 += partial[(long)r * N + col];
+      a1 += partial[(long)(r + 8) * N + col];
+    }
+    if (r < R) a0 += partial[(long)r * N + col];
+  }
+  red[rl][c] = a0 + a1;
+  __syncthreads();
+  if (rl == 0 && col < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    if (col < D) dgamma[col] = t;
+    else if (col < 2 * D) dbeta[col - D] = t;
+    else if (dx_dtype == 0) reinterpret_cast<half_t*>(dxsum)[col - 2 * D] = (half_t)t;
+    else reinterpret_cast<float*>(dxsum)[col - 2 * D] = t;
   }
 }
 
@@ -352,28 +383,33 @@ extern "C" int hmmc_layernorm_fwd(const void* x, const float* gamma, const float
 extern "C" size_t hmmc_layernorm_bwd_workspace(int rows, int D) {
   int nb = (rows + 3) / 4;
   if (nb > 1024) nb = 1024;
-  return (size_t)nb * 2 * D * sizeof(float);
+  return (size_t)nb * 3 * D * sizeof(float);
 }
 
 // dx rows are written at the same (row_index, in_stride) positions the forward read x from.
+// dx_colsum (optional, dtype of dx, [D]): sum over rows of the dx rows written, i.e. the bias gradient of the linear
+// layer whose output this LayerNorm's input is; saves a separate pass over dx.
 extern "C" int hmmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                  const void* dres, void* dx, float* dgamma, float* dbeta, const int* row_index, int rows,
-                                  int D, long in_stride, int dtype, void* workspace, size_t ws_bytes, hipStream_t stream) {
+                                  const void* dres, void* dx, float* dgamma, float* dbeta, void* dx_colsum,
+                                  const int* row_index, int rows, int D, long in_stride, int dtype, void* workspace,
+                                  size_t ws_bytes, hipStream_t stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return HMMC_ERR_ARG;
   int vn = dtype == 0 ? 8 : 4;
   if (D % vn || D > LN_MAXD || in_stride % vn) return HMMC_ERR_UNSUPPORTED;
   int nb = (rows + 3) / 4;
   if (nb > 1024) nb = 1024;
-  if (!workspace || ws_bytes < (size_t)nb * 2 * D * sizeof(float)) return HMMC_ERR_WORKSPACE;
+  const int np = dx_colsum ? 3 : 2;
+  if (!workspace || ws_bytes < (size_t)nb * np * D * sizeof(float)) return HMMC_ERR_WORKSPACE;
   float* partial = (float*)workspace;
   if (dtype == 0)
     hipLaunchKernelGGL(ln_bwd_kernel<half_t>, dim3(nb), dim3(256), 0, stream, (const half_t*)dy, (const half_t*)x, gamma,
-                       mean, rstd, (const half_t*)dres, (half_t*)dx, partial, row_index, rows, D, in_stride);
+                       mean, rstd, (const half_t*)dres, (half_t*)dx, partial, row_index, rows, D, in_stride, dx_colsum != nullptr);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)dy, (const float*)x, gamma, mean,
-                       rstd, (const float*)dres, (float*)dx, partial, row_index, rows, D, in_stride);
-  hipLaunchKernelGGL(colreduce_kernel<float>, dim3((2 * D + 31) / 32), dim3(256), 0, stream, (const float*)partial, dgamma,
-                     dbeta, nb, 2 * D, D, 0);
+                       rstd, (const float*)dres, (float*)dx, partial, row_index, rows, D, in_stride, dx_colsum != nullptr);
+  // one reduce over the np*D partial columns: [0,D) dgamma, [D,2D) dbeta (fp32), [2D,3D) dx_colsum (dtype of dx)
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3((np * D + 31) / 32), dim3(256), 0, stream, (const float*)partial, dgamma, dbeta,
+                     dx_colsum, dtype, nb, np * D, D);
   return hmmc_launch_status();
 }
 

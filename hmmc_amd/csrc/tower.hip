@@ -19,19 +19,20 @@ int hmmc_gemm_f32(const float*, const float*, float*, int, int, int, long, long,
 int hmmc_layernorm_fwd(const void*, const float*, const float*, void*, float*, float*, const int*, int, int, long, float, int,
                        hipStream_t);
 int hmmc_layernorm_bwd(const void*, const void*, const float*, const float*, const float*, const void*, void*, float*, float*,
-                       const int*, int, int, long, int, void*, size_t, hipStream_t);
+                       void*, const int*, int, int, long, int, void*, size_t, hipStream_t);
 size_t hmmc_layernorm_bwd_workspace(int, int);
 int hmmc_colsum(const void*, void*, int, int, long, int, int, int, void*, size_t, hipStream_t);
 size_t hmmc_colsum_workspace(int, int);
 int hmmc_attention_f16_fwd(const void*, void*, float*, int, int, int, int, hipStream_t);
-int hmmc_attention_f16_bwd(const void*, const void*, const float*, const void*, void*, int, int, int, int, hipStream_t);
+int hmmc_attention_f16_bwd(const void*, const void*, const float*, const void*, void*, float*, int, int, int, int, hipStream_t);
+size_t hmmc_gemm_f16_colsum_rows(int, int, int);
 int hmmc_temporal_attention_fwd(const float*, float*, float*, int, int, int, int, hipStream_t);
 int hmmc_temporal_attention_bwd(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
 }
 
 namespace {
 
-enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8 };
+enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -72,12 +73,14 @@ inline int linear(bool f32, const void* x, const void* w, void* y, int M, int N,
                        epi | (bias ? EPI_BIAS : 0) | (resid ? EPI_RESID : 0), nullptr, 0, s);
 }
 // dx[M,K'] = dy[M,N'] w[N',K']
+// csum (fp16 tower only): fp32 partial column sums of dx, hmmc_gemm_f16_colsum_rows(M, K', N') rows of K' floats
 inline int dgrad(bool f32, const void* dy, const void* w, void* dx, int M, int Np, int Kp, const void* aux_in, int epi,
-                 hipStream_t s) {
+                 hipStream_t s, float* csum = nullptr, size_t csum_bytes = 0) {
   if (f32)
     return hmmc_gemm_f32((const float*)dy, (const float*)w, (float*)dx, M, Kp, Np, Np, 1, Kp, 1, Kp, 1.0f, nullptr, nullptr,
                          nullptr, (const float*)aux_in, epi, s);
-  return hmmc_gemm_f16(dy, w, dx, M, Kp, Np, Np, Kp, Kp, 1, 0, nullptr, nullptr, nullptr, aux_in, epi, nullptr, 0, s);
+  return hmmc_gemm_f16(dy, w, dx, M, Kp, Np, Np, Kp, Kp, 1, 0, nullptr, nullptr, nullptr, aux_in, epi | (csum ? EPI_COLSUM : 0),
+                       csum, csum_bytes, s);
 }
 // dW[N',K'] = dy[T,N']^T x[T,K']
 inline int wgrad(bool f32, const void* dy, const void* x, void* dw, int T, int Np, int Kp, void* ws, size_t wsb, hipStream_t s) {
@@ -103,7 +106,15 @@ extern "C" size_t hmmc_tower_bwd_scratch_bytes(long tokens, int D, int fp32) {
   return al((size_t)tokens * 4 * D * es) + al((size_t)tokens * 3 * D * es) + 4 * al((size_t)tokens * D * es);
 }
 
-extern "C" size_t hmmc_tower_workspace_bytes(long tokens, int D, int fp32) {
+// fp32 partial sums of the fused bias gradients (fp16 tower): c_fc bias from the QuickGELU' dgrad epilogue
+// [colsum_rows][4D], in_proj bias from the attention backward [nseq][3D]; one region, used one after the other
+static size_t partial_bytes(long tokens, int D, int nseq) {
+  size_t a = hmmc_gemm_f16_colsum_rows((int)tokens, 4 * D, D) * (size_t)4 * D * sizeof(float);
+  size_t b = (size_t)nseq * 3 * D * sizeof(float);
+  return al(a > b ? a : b);
+}
+
+static size_t general_bytes(long tokens, int D, int fp32) {
   size_t w = hmmc_layernorm_bwd_workspace((int)tokens, D);
   size_t c = hmmc_colsum_workspace((int)tokens, 4 * D);
   if (c > w) w = c;
@@ -118,6 +129,11 @@ extern "C" size_t hmmc_tower_workspace_bytes(long tokens, int D, int fp32) {
     if (g > w) w = g;
   }
   return al(w);
+}
+
+// [general: LayerNorm / column-sum / split-K slabs][fp16 tower: bias-gradient partials]
+extern "C" size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32) {
+  return general_bytes(tokens, D, fp32) + (fp32 ? 0 : partial_bytes(tokens, D, nseq));
 }
 
 // y = tower(x).  keep_acts: acts holds nlayers slabs (training); otherwise one slab is reused (key encoders, eval).
@@ -171,7 +187,15 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
   void* ping[2];
   ping[0] = sp; sp += al((size_t)T * D * es);
   ping[1] = sp;
+  // workspace = [general][partials]; the fp16 tower takes three of its four bias gradients from the kernels that
+  // produce the tensors (LayerNorm backward: out_proj / c_proj; QuickGELU' dgrad epilogue: c_fc; attention backward:
+  // in_proj) instead of re-reading them.  Only the c_proj bias of the LAST layer still needs its own pass over dy.
+  const size_t gen = general_bytes(T, D, fp32);
+  const size_t part_bytes = f32 ? 0 : partial_bytes(T, D, nseq);
+  if (ws_bytes < gen + part_bytes) return HMMC_ERR_WORKSPACE;
+  float* part = f32 ? nullptr : (float*)((char*)workspace + gen);
   const void* g_in = dy;
+  CK(hmmc_colsum(dy, grads[(size_t)(nlayers - 1) * 12 + 11], (int)T, D, D, dt, dt, 0, workspace, gen, s));
   for (int i = nlayers - 1; i >= 0; --i) {
     const void* const* P = params + (size_t)i * 12;
     void* const* G = grads + (size_t)i * 12;
@@ -179,25 +203,37 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
     const void* xin = i == 0 ? x0 : (const void*)a.x;
     void* g_out = i == 0 ? dx : ping[i & 1];
     // MLP: x2 = x1 + c_proj(QuickGELU(c_fc(ln2)))
-    CK(wgrad(f32, g_in, a.g, G[10], (int)T, D, 4 * D, workspace, ws_bytes, s));
-    CK(hmmc_colsum(g_in, G[11], (int)T, D, D, dt, dt, 0, workspace, ws_bytes, s));
-    CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_DGELU, s));
-    CK(wgrad(f32, dh, a.ln2, G[8], (int)T, 4 * D, D, workspace, ws_bytes, s));
-    CK(hmmc_colsum(dh, G[9], (int)T, 4 * D, 4 * D, dt, dt, 0, workspace, ws_bytes, s));
+    CK(wgrad(f32, g_in, a.g, G[10], (int)T, D, 4 * D, workspace, gen, s));
+    if (f32) {
+      CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_DGELU, s));
+      CK(hmmc_colsum(dh, G[9], (int)T, 4 * D, 4 * D, dt, dt, 0, workspace, gen, s));
+    } else {
+      const int rows = (int)hmmc_gemm_f16_colsum_rows((int)T, 4 * D, D);
+      CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_DGELU, s, part, part_bytes));
+      CK(hmmc_colsum(part, G[9], rows, 4 * D, 4 * D, 1, dt, 0, workspace, gen, s));
+    }
+    CK(wgrad(f32, dh, a.ln2, G[8], (int)T, 4 * D, D, workspace, gen, s));
     CK(dgrad(f32, dh, P[8], dln, (int)T, 4 * D, D, nullptr, 0, s));
-    CK(hmmc_layernorm_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], nullptr, (int)T, D, D,
-                          dt, workspace, ws_bytes, s));
+    CK(hmmc_layernorm_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], G[5], nullptr,
+                          (int)T, D, D, dt, workspace, gen, s));               // G[5]: out_proj bias = colsum(dx1)
     // attention: x1 = x + out_proj(attn(in_proj(ln1)))
-    CK(wgrad(f32, dx1, a.att, G[4], (int)T, D, D, workspace, ws_bytes, s));
-    CK(hmmc_colsum(dx1, G[5], (int)T, D, D, dt, dt, 0, workspace, ws_bytes, s));
+    CK(wgrad(f32, dx1, a.att, G[4], (int)T, D, D, workspace, gen, s));
     CK(dgrad(f32, dx1, P[4], dln, (int)T, D, D, nullptr, 0, s));                 // datt (reuses dln)
-    if (f32) CK(hmmc_temporal_attention_bwd((const float*)a.qkv, a.stat, (const float*)dln, (float*)dqkv, nseq, L, heads, s));
-    else CK(hmmc_attention_f16_bwd(a.qkv, a.att, a.stat, dln, dqkv, nseq, L, heads, causal, s));
-    CK(wgrad(f32, dqkv, a.ln1, G[2], (int)T, 3 * D, D, workspace, ws_bytes, s));
-    CK(hmmc_colsum(dqkv, G[3], (int)T, 3 * D, 3 * D, dt, dt, 0, workspace, ws_bytes, s));
+    if (f32) {
+      CK(hmmc_temporal_attention_bwd((const float*)a.qkv, a.stat, (const float*)dln, (float*)dqkv, nseq, L, heads, s));
+      CK(hmmc_colsum(dqkv, G[3], (int)T, 3 * D, 3 * D, dt, dt, 0, workspace, gen, s));
+    } else if (L <= 64) {
+      CK(hmmc_attention_f16_bwd(a.qkv, a.att, a.stat, dln, dqkv, part, nseq, L, heads, causal, s));
+      CK(hmmc_colsum(part, G[3], nseq, 3 * D, 3 * D, 1, dt, 0, workspace, gen, s));
+    } else {
+      CK(hmmc_attention_f16_bwd(a.qkv, a.att, a.stat, dln, dqkv, nullptr, nseq, L, heads, causal, s));
+      CK(hmmc_colsum(dqkv, G[3], (int)T, 3 * D, 3 * D, dt, dt, 0, workspace, gen, s));
+    }
+    CK(wgrad(f32, dqkv, a.ln1, G[2], (int)T, 3 * D, D, workspace, gen, s));
     CK(dgrad(f32, dqkv, P[2], dln, (int)T, 3 * D, D, nullptr, 0, s));
-    CK(hmmc_layernorm_bwd(dln, xin, (const float*)P[0], a.m1, a.r1, dx1, g_out, (float*)G[0], (float*)G[1], nullptr, (int)T, D, D,
-                          dt, workspace, ws_bytes, s));
+    // the c_proj bias gradient of the layer below is the column sum of the dx this call writes
+    CK(hmmc_layernorm_bwd(dln, xin, (const float*)P[0], a.m1, a.r1, dx1, g_out, (float*)G[0], (float*)G[1],
+                          i > 0 ? grads[(size_t)(i - 1) * 12 + 11] : nullptr, nullptr, (int)T, D, D, dt, workspace, gen, s));
     g_in = g_out;
   }
   return HMMC_OK;

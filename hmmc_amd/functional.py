@@ -94,7 +94,7 @@ def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep):
     nl = len(params) // PER_LAYER
     slab = query("hmmc_tower_act_bytes", T, D, nseq, L, heads, int(fp32))
     acts = torch.empty(slab * (nl if keep else 1), dtype=torch.uint8, device=x.device)
-    wsb = query("hmmc_tower_workspace_bytes", T, D, int(fp32))
+    wsb = query("hmmc_tower_workspace_bytes", T, D, nseq, int(fp32))
     ws = ops.workspace(wsb, x.device, "tower")
     y = torch.empty_like(x)
     call("hmmc_tower_fwd", ptr(x), ptr(y), _ptr_array(params), ptr(acts), int(keep), nseq, L, heads, D, nl, int(causal),
@@ -108,7 +108,7 @@ def _tower_backward(dy, x0, params, acts, nseq, L, heads, causal, fp32):
     nl = len(params) // PER_LAYER
     grads = [torch.empty_like(p) for p in params]
     scratch = torch.empty(query("hmmc_tower_bwd_scratch_bytes", T, D, int(fp32)), dtype=torch.uint8, device=x0.device)
-    wsb = query("hmmc_tower_workspace_bytes", T, D, int(fp32))
+    wsb = query("hmmc_tower_workspace_bytes", T, D, nseq, int(fp32))
     ws = ops.workspace(wsb, x0.device, "tower")
     dx = torch.empty_like(x0)
     call("hmmc_tower_bwd", ptr(dy), ptr(dx), ptr(x0), _ptr_array(params), _ptr_array(grads), ptr(acts), ptr(scratch), nseq, L,

@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import call, ptr, query
 
 EPI_BIAS, EPI_RESID, EPI_QGELU, EPI_DGELU = 1, 2, 4, 8
+EPI_COLSUM = 32
 
 _ws_cache = {}
 
@@ -50,7 +51,7 @@ def _chk(t, dtype, name):
 
 
 def gemm_f16(a, b, M, N, K, a_kmajor=True, b_kmajor=True, bias=None, resid=None, aux_in=None, epilogue=0,
-             want_aux=False, out=None):
+             want_aux=False, out=None, want_colsum=False):
     """C[M,N] = epi(Aop[M,K] @ Bop[N,K]^T).  a: [M,K] if a_kmajor else [K,M]; b: [N,K] if b_kmajor else [K,N]."""
     _chk(a, torch.float16, "a")
     _chk(b, torch.float16, "b")
@@ -71,6 +72,12 @@ def gemm_f16(a, b, M, N, K, a_kmajor=True, b_kmajor=True, bias=None, resid=None,
         epilogue |= EPI_RESID
     if aux_in is not None:
         assert tuple(aux_in.shape) == (M, N)
+    if want_colsum:                               # fp32 partial column sums of C, one row per 128 / 64 output rows
+        rows = query("hmmc_gemm_f16_colsum_rows", M, N, K)
+        part = torch.empty((rows, N), dtype=torch.float32, device=a.device)
+        call("hmmc_gemm_f16", ptr(a), ptr(b), ptr(c), M, N, K, a.shape[1], b.shape[1], N, int(a_kmajor), int(b_kmajor),
+             ptr(bias), ptr(resid), ptr(aux_out), ptr(aux_in), epilogue | EPI_COLSUM, ptr(part), part.numel() * 4)
+        return (c, aux_out, part) if want_aux else (c, part)
     wsb = 0 if epilogue else query("hmmc_gemm_f16_workspace", M, N, K)
     ws = workspace(wsb, a.device, "gemm") if wsb else None
     call("hmmc_gemm_f16", ptr(a), ptr(b), ptr(c), M, N, K, a.shape[1], b.shape[1], N, int(a_kmajor), int(b_kmajor),
@@ -98,8 +105,8 @@ def layernorm_fwd(x, gamma, beta, eps, rows=None, row_index=None, in_stride=None
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, row_index=None, dx=None):
-    """Returns (dx, dgamma, dbeta).  With row_index, dx must be a pre-zeroed tensor shaped like x."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, row_index=None, dx=None, want_colsum=False):
+    """Returns (dx, dgamma, dbeta[, colsum(dx)]).  With row_index, dx must be a pre-zeroed tensor shaped like x."""
     D = x.shape[-1]
     dt = 0 if x.dtype == torch.float16 else 1
     rows = mean.numel()
@@ -114,9 +121,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, row_index=None, dx=None):
     dbeta = torch.empty(D, dtype=torch.float32, device=x.device)
     wsb = query("hmmc_layernorm_bwd_workspace", rows, D)
     ws = workspace(wsb, x.device, "ln")
+    dxs = torch.empty(D, dtype=x.dtype, device=x.device) if want_colsum else None
     call("hmmc_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dgamma),
-         ptr(dbeta), ptr(row_index), rows, D, D, dt, ptr(ws), wsb)
-    return dx, dgamma, dbeta
+         ptr(dbeta), ptr(dxs), ptr(row_index), rows, D, D, dt, ptr(ws), wsb)
+    return (dx, dgamma, dbeta, dxs) if want_colsum else (dx, dgamma, dbeta)
 
 
 def colsum(x2d, out_dtype=None, round_f16=False):
@@ -181,11 +189,13 @@ def attention_f16_fwd(qkv, nseq, L, H, causal):
     return out, lse
 
 
-def attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal):
+def attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=False):
+    """-> dqkv [, per-sequence column sums of dqkv: fp32 [nseq, 3*64*H] (L <= 64)]"""
     _chk(dout, torch.float16, "dout")
     dqkv = torch.empty_like(qkv)
-    call("hmmc_attention_f16_bwd", ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), nseq, L, H, int(causal))
-    return dqkv
+    part = torch.empty((nseq, qkv.shape[1]), dtype=torch.float32, device=qkv.device) if want_dbias else None
+    call("hmmc_attention_f16_bwd", ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), ptr(part), nseq, L, H, int(causal))
+    return (dqkv, part) if want_dbias else dqkv
 
 
 # ----------------------------------------------------------------------------- fp32 side

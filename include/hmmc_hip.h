@@ -35,6 +35,7 @@ typedef void* hmmc_stream_t; /* hipStream_t */
 #define HMMC_EPI_RESID 2 /* out = fp16(resid + fp16(acc + bias))        */
 #define HMMC_EPI_QGELU 4 /* out = QuickGELU(h), aux_out = h = fp16(acc + bias) */
 #define HMMC_EPI_DGELU 8 /* out = acc * QuickGELU'(aux_in)              */
+#define HMMC_EPI_COLSUM 32 /* + fp32 partial column sums of C into `workspace` (see hmmc_gemm_f16_colsum_rows) */
 
 /* fp16 MFMA GEMM, fp32 accumulate: C[M,N] = epilogue(sum_k Aop[m][k] * Bop[n][k]).
  * a_kmajor: Aop[m][k] = A[m*lda + k], else A[k*lda + m]; likewise b_kmajor for B (rows n).
@@ -44,6 +45,11 @@ typedef void* hmmc_stream_t; /* hipStream_t */
  * Without an epilogue, small-output/long-K problems (weight gradients) are split over K into
  * fp32 slabs in `workspace` (hmmc_gemm_f16_workspace bytes; may be NULL to disable). */
 size_t hmmc_gemm_f16_workspace(int M, int N, int K);
+/* With HMMC_EPI_COLSUM (32) in `epilogue` (any epilogue, no split-K) `workspace` instead receives fp32 partial column
+ * sums of the fp16 values written to C: hmmc_gemm_f16_colsum_rows(M, N, K) rows of N floats, one per 128 (or 64) output
+ * rows; hmmc_colsum over them gives the bias gradient of the layer that produced C's pre-image (c_fc at
+ * module_clip.py:240) without re-reading C. */
+size_t hmmc_gemm_f16_colsum_rows(int M, int N, int K);
 /* Benchmark-only live timing of every hmmc_gemm_f16 launch with HIP events on the launch stream; stop() synchronises and
  * returns, per operand layout (0 forward, 1 dgrad, 2 wgrad), the summed 2MNK flops, algorithmic operand bytes, seconds and launch counts. */
 int hmmc_gemm_profile_start(void);
@@ -60,10 +66,12 @@ int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, in
 int hmmc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                        const int* row_index, int rows, int D, long in_stride, float eps, int dtype, hmmc_stream_t stream);
 size_t hmmc_layernorm_bwd_workspace(int rows, int D);
-/* dx[row] = LN'(dy)[row] + (dres ? dres[row] : 0), written at the rows the forward read. */
+/* dx[row] = LN'(dy)[row] + (dres ? dres[row] : 0), written at the rows the forward read.  dx_colsum (optional, [D],
+ * dtype of dx) receives the column sums of the dx rows written: the bias gradient of the linear layer whose output feeds
+ * this LayerNorm's input (out_proj / c_proj bias at module_clip.py:235-246), without a second pass over dx. */
 int hmmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                       const void* dres, void* dx, float* dgamma, float* dbeta, const int* row_index, int rows, int D,
-                       long in_stride, int dtype, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+                       const void* dres, void* dx, float* dgamma, float* dbeta, void* dx_colsum, const int* row_index,
+                       int rows, int D, long in_stride, int dtype, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
 
 /* out[n] = sum_m X[m][n] (bias, class/positional-embedding gradients). dtypes: 0 fp16, 1 fp32. */
 size_t hmmc_colsum_workspace(int M, int N);
@@ -90,8 +98,10 @@ int hmmc_cast(const void* in, void* out, long n, int kind, hmmc_stream_t stream)
  * Replaces the attention core of nn.MultiheadAttention at modules/module_clip.py:251. */
 int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, int nseq, int L, int H, int causal,
                            hmmc_stream_t stream);
-int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, int nseq,
-                           int L, int H, int causal, hmmc_stream_t stream);
+/* dbias_partial (optional, fp32 [nseq][3*64*H], L <= 64 only): per-sequence column sums of dqkv, i.e. partial sums of
+ * the in-projection bias gradient; the caller finishes with hmmc_colsum over the nseq rows instead of re-reading dqkv. */
+int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
+                           float* dbias_partial, int nseq, int L, int H, int causal, hmmc_stream_t stream);
 
 /* fp32 MFMA GEMM (exact f32 FMA chain) with general strides: C[m][n] = epi(alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]);
  * one stride of each operand must be 1.  Epilogue flags as hmmc_gemm_f16 plus HMMC_EPI_RELU; QuickGELU is evaluated in fp32.
@@ -194,7 +204,7 @@ int hmmc_ce_bwd(float* logits, const long* labels, const float* lse, const float
  * hmmc_tower_workspace_bytes().  Only sequences this library's kernels on `stream`. */
 size_t hmmc_tower_act_bytes(long tokens, int D, int nseq, int L, int heads, int fp32);
 size_t hmmc_tower_bwd_scratch_bytes(long tokens, int D, int fp32);
-size_t hmmc_tower_workspace_bytes(long tokens, int D, int fp32);
+size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32);
 int hmmc_tower_fwd(const void* x, void* y, const void* const* params, void* acts, int keep_acts, int nseq, int L, int heads,
                    int D, int nlayers, int causal, float eps, int fp32, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
 int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads, const void* acts,

@@ -98,6 +98,22 @@ def test_gemm_random_and_epilogues():
     assert relerr(dh, dref) < 2e-3
 
 
+@pytest.mark.parametrize("M,N,K,b_kmajor", [(1000, 384, 256, True), (4096, 768, 256, False), (2048 + 77, 512, 128, False)])
+def test_gemm_fused_column_sums(M, N, K, b_kmajor):
+    """EPI_COLSUM: partial column sums of the fp16 values written (bias gradient without re-reading C)."""
+    a = rnd(M, K, scale=0.5)
+    w = rnd(N, K, scale=0.1, seed=1) if b_kmajor else rnd(K, N, scale=0.1, seed=1)
+    h = rnd(M, N, seed=2)
+    c, part = ops.gemm_f16(a, w, M, N, K, b_kmajor=b_kmajor, aux_in=h, epilogue=ops.EPI_DGELU, want_colsum=True)
+    c2 = ops.gemm_f16(a, w, M, N, K, b_kmajor=b_kmajor, aux_in=h, epilogue=ops.EPI_DGELU)
+    assert torch.equal(c, c2)
+    ref = c.float().sum(0)
+    got = part.sum(0)
+    assert float((got - ref).abs().max()) < 1e-3 * float(ref.abs().max()) + 1e-3
+    assert torch.equal(ops.colsum(part, out_dtype=torch.float16), ops.colsum(c)) or \
+        float((ops.colsum(part, out_dtype=torch.float16).float() - ops.colsum(c).float()).abs().max()) < 2e-2
+
+
 # ----------------------------------------------------------------------------- LayerNorm / rows
 
 @pytest.mark.parametrize("dtype,D,eps", [(torch.float16, 768, 1e-5), (torch.float16, 128, 1e-5), (torch.float32, 512, 1e-12)])
@@ -117,6 +133,9 @@ def test_layernorm_fwd_bwd(dtype, D, eps):
     dx, dg, db = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres=dres)
     assert relerr(dx, xr.grad + dres.float()) < tol
     assert relerr(dg, gr.grad) < 1e-4 and relerr(db, br.grad) < 1e-4
+    dx2, dg2, db2, cs = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres=dres, want_colsum=True)   # fused colsum(dx)
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    assert cs.dtype == dtype and relerr(cs, dx.float().sum(0)) < (2e-3 if dtype == torch.float16 else 1e-5)
 
 
 def test_layernorm_row_gather():
@@ -205,3 +224,8 @@ def test_attention_fwd_bwd(nseq, L, H, causal):
     for i, nm in enumerate("qkv"):
         e = relerr(d[:, i], g[:, i])
         assert e < 8e-3, f"d{nm} rel err {e}"
+    if L <= 64:                                   # fused in_proj bias-gradient partials: per-sequence column sums of dqkv
+        dqkv2, part = ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=True)
+        assert torch.equal(dqkv, dqkv2)
+        ref = dqkv.float().view(nseq, L, 3 * D).sum(1)
+        assert float((part - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-4
