@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // Rows are read through the same optional row_index / in_stride as the forward; dx rows are
 // written to dx + dst_row * out_stride where dst_row = row_index ? row_index[row] : row.
 template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ partial,
@@ -98,22 +98,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     const T* xr = x + src_row * in_stride;
     const T* dyr = dy + (long)row * D;
     const float mean = mean_in[row], rstd = rstd_in[row];
-    float xh[LN_MAXV][VN], g[LN_MAXV][VN];
+    // the row stays in registers as loaded (packed); xhat and g are recomputed for the second sweep instead of
+    // being held as fp32 arrays: 16 VGPRs instead of 32 for a half row, which keeps 4 waves per SIMD resident
+    V tx[LN_MAXV], td[LN_MAXV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       int c = lane + 64 * i;
       if (c < nchunk) {
-        V tx = *reinterpret_cast<const V*>(xr + c * VN);
-        V td = *reinterpret_cast<const V*>(dyr + c * VN);
+        tx[i] = *reinterpret_cast<const V*>(xr + c * VN);
+        td[i] = *reinterpret_cast<const V*>(dyr + c * VN);
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
-          float d = (float)td[j];
-          xh[i][j] = ((float)tx[j] - mean) * rstd;
-          g[i][j] = d * gamma[c * VN + j];
-          s1 += g[i][j];
-          s2 += g[i][j] * xh[i][j];
-          dg[i][j] += d * xh[i][j];
+          float d = (float)td[i][j];
+          float xh = ((float)tx[i][j] - mean) * rstd;
+          float g = d * gamma[c * VN + j];
+          s1 += g;
+          s2 += g * xh;
+          dg[i][j] += d * xh;
           db[i][j] += d;
         }
       }
@@ -131,7 +133,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         if (drr) rr = *reinterpret_cast<const V*>(drr + c * VN);
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
-          float val = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+          float xh = ((float)tx[i][j] - mean) * rstd;
+          float g = (float)td[i][j] * gamma[c * VN + j];
+          float val = rstd * (g - s1 - xh * s2);
           if (drr) val += (float)rr[j];
           o[j] = (T)val;
           ds[i][j] += (float)o[j];
