@@ -45,14 +45,15 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float r16(float x) { return (float)(half_t)x; }
 
 // QuickGELU evaluated with the reference's fp16 rounding points
-// (modules/module_clip.py:226-228: x * sigmoid(1.702 * x) on an fp16 tensor).
+// (modules/module_clip.py:226-228: x * sigmoid(1.702 * x) on an fp16 tensor).  exp(-t) = exp2(-log2(e) t): one
+// multiply + v_exp_f32; v_rcp_f32 is 1 ulp, far inside the fp16 rounding that follows.
 __device__ __forceinline__ float qgelu_f16(float h) {
   float t = r16(1.702f * h);
-  float s = r16(__builtin_amdgcn_rcpf(1.0f + __expf(-t)));      // v_rcp_f32: 1 ulp, far inside the fp16 rounding that follows
+  float s = r16(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)));
   return r16(h * s);
 }
-// d/dh [h * sigmoid(1.702 h)]
+// d/dh [h * sigmoid(1.702 h)] = s + 1.702 h s (1 - s)
 __device__ __forceinline__ float qgelu_grad(float h) {
-  float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * h));
-  return s * (1.0f + 1.702f * h * (1.0f - s));
+  float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(h * (-1.702f * 1.4426950408889634f)));
+  return __builtin_fmaf(1.702f * h * (1.0f - s), s, s);
 }

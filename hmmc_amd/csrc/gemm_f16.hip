@@ -177,7 +177,8 @@ __device__ __forceinline__ void to_store_order(u4& x, u4& y) {
 // F >= 0: the epilogue flags at compile time; F < 0: p.flags at run time
 template <int MT, int F>
 __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
-  const int flags = F >= 0 ? F : (p.flags & ~EPI_COLSUM);
+  const int flags = F >= 0 ? (F & ~EPI_COLSUM) : (p.flags & ~EPI_COLSUM);
+  const bool want_csum = F >= 0 ? (F & EPI_COLSUM) != 0 : p.csum != nullptr;
   const int c = lane & 15, g = lane >> 4;
   const int n_l = 32 * (c >> 3) + 16 * (g & 1) + 8 * (g >> 1);   // this lane's 8 columns within the wave's 64
   const bool n_ok = n0 + n_l < p.N;                              // N % 8 == 0: a 16-byte piece is all-in or all-out
@@ -261,12 +262,19 @@ __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4
         for (int r = 0; r < 4; ++r) out[j][r] = (half_t)v[r];
       }
     }
-    if (p.csum) {
-      const bool row_ok = m_base + 16 * i + c < p.M;
+    if (want_csum) {
+      if (full) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) csum[j][r] += row_ok ? (float)out[j][r] : 0.f;
+          for (int r = 0; r < 4; ++r) csum[j][r] += (float)out[j][r];
+      } else {
+        const bool row_ok = m_base + 16 * i + c < p.M;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) csum[j][r] += row_ok ? (float)out[j][r] : 0.f;
+      }
     }
     {
       u4 o0 = join(out[0], out[1]), o1 = join(out[2], out[3]);
@@ -281,7 +289,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4
       store2(p.aux_out, i, o0, o1);
     }
   }
-  if (p.csum) {                                  // 16 lanes c -> one partial row per wave: row block (m_base / (16 MT))
+  if (want_csum) {                               // 16 lanes c -> one partial row per wave: row block (m_base / (16 MT))
     float* dst = p.csum + (size_t)(m_base / (16 * MT)) * p.N + n0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -301,16 +309,11 @@ __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4
   }
 }
 
-template <int MT>
+// EPI >= 0: the kernel was instantiated for exactly these flags (straight-line epilogue, its own register budget);
+// EPI < 0: generic kernel, flags read at run time
+template <int MT, int EPI>
 __device__ __forceinline__ void epilogue_f16(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
-  switch (p.flags & ~EPI_COLSUM) {              // the combinations the towers use get straight-line code
-    case 0: epilogue_impl<MT, 0>(p, acc, m_base, n0, lane); break;
-    case EPI_BIAS: epilogue_impl<MT, EPI_BIAS>(p, acc, m_base, n0, lane); break;
-    case EPI_BIAS | EPI_RESID: epilogue_impl<MT, EPI_BIAS | EPI_RESID>(p, acc, m_base, n0, lane); break;
-    case EPI_BIAS | EPI_QGELU: epilogue_impl<MT, EPI_BIAS | EPI_QGELU>(p, acc, m_base, n0, lane); break;
-    case EPI_DGELU: epilogue_impl<MT, EPI_DGELU>(p, acc, m_base, n0, lane); break;
-    default: epilogue_impl<MT, -1>(p, acc, m_base, n0, lane); break;
-  }
+  epilogue_impl<MT, EPI>(p, acc, m_base, n0, lane);
 }
 
 // split-K partial sums: fp32 slab [split][M][N], 16-byte stores straight from the MFMA layout
@@ -333,8 +336,8 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, f4 (&acc)[MT][N
 // Persistent: the grid is sized to the chip and every workgroup walks work items (output tile x K-split)
 // item, item + gridDim, ...  The LDS-DMA prefetch runs one K-tile ahead across item boundaries, so the
 // first tile of the next output tile is already in flight while this one's epilogue stores drain.
-template <bool AK, bool BK, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
+template <bool AK, bool BK, int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
   constexpr int NTH = 64 * WM * WN;
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
   constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_kernel(GemmArgs p) {
     if (p.splitk > 1)
       epilogue_slab<MT, NT>(p, acc, tm * BM + wm * (MT * 16) + (lane & 15), tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
     else
-      epilogue_f16<MT>(p, acc, tm * BM + wm * (MT * 16), tn * BN + wn * (NT * 16), lane);
+      epilogue_f16<MT, EPI>(p, acc, tm * BM + wm * (MT * 16), tn * BN + wn * (NT * 16), lane);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -606,21 +609,39 @@ TileCfg pick_cfg(int M, int N, int K, bool allow_split) {
   return c;
 }
 
-template <int BM, int BN, int WM, int WN>
-void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stream) {
+template <bool AK, bool BK, int BM, int BN, int WM, int WN, int EPI>
+void launch_one(const GemmArgs& p, dim3 grid, hipStream_t stream) {
   constexpr int SMEM = 2 * (BM + BN) * BKT * 2;
-  dim3 block(64 * WM * WN);
   if (SMEM > 64 * 1024) {
-    static bool once = (hmmc_allow_lds((const void*)gemm_f16_kernel<true, true, BM, BN, WM, WN>, SMEM),
-                        hmmc_allow_lds((const void*)gemm_f16_kernel<true, false, BM, BN, WM, WN>, SMEM),
-                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, true, BM, BN, WM, WN>, SMEM),
-                        hmmc_allow_lds((const void*)gemm_f16_kernel<false, false, BM, BN, WM, WN>, SMEM), true);
+    static bool once = (hmmc_allow_lds((const void*)gemm_f16_kernel<AK, BK, BM, BN, WM, WN, EPI>, SMEM), true);
     (void)once;
   }
-  if (ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<true, true, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
-  else if (ak && !bk) hipLaunchKernelGGL((gemm_f16_kernel<true, false, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
-  else if (!ak && bk) hipLaunchKernelGGL((gemm_f16_kernel<false, true, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
-  else hipLaunchKernelGGL((gemm_f16_kernel<false, false, BM, BN, WM, WN>), grid, block, SMEM, stream, p);
+  hipLaunchKernelGGL((gemm_f16_kernel<AK, BK, BM, BN, WM, WN, EPI>), grid, dim3(64 * WM * WN), SMEM, stream, p);
+}
+
+// One kernel per (operand layout, epilogue) the towers use, so that a heavy epilogue (QuickGELU, residual reads, column
+// sums) cannot cost the plain kernels registers; every other combination runs the generic kernel (EPI = -1).
+template <int BM, int BN, int WM, int WN>
+void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stream) {
+  const int f = p.csum ? -1 : p.flags;
+  if (ak && bk) {                 // forward: y = x W^T
+    switch (f) {
+      case 0: return launch_one<true, true, BM, BN, WM, WN, 0>(p, grid, stream);
+      case EPI_BIAS: return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS>(p, grid, stream);
+      case EPI_BIAS | EPI_RESID: return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS | EPI_RESID>(p, grid, stream);
+      case EPI_BIAS | EPI_QGELU: return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS | EPI_QGELU>(p, grid, stream);
+      default: return launch_one<true, true, BM, BN, WM, WN, -1>(p, grid, stream);
+    }
+  } else if (ak && !bk) {         // dgrad: dx = dy W
+    if (f == 0) return launch_one<true, false, BM, BN, WM, WN, 0>(p, grid, stream);
+    if (p.csum && (p.flags & ~EPI_COLSUM) == EPI_DGELU) return launch_one<true, false, BM, BN, WM, WN, EPI_DGELU | EPI_COLSUM>(p, grid, stream);
+    if (f == EPI_DGELU) return launch_one<true, false, BM, BN, WM, WN, EPI_DGELU>(p, grid, stream);
+    return launch_one<true, false, BM, BN, WM, WN, -1>(p, grid, stream);
+  } else if (!ak && !bk) {        // wgrad: dW = dy^T x
+    if (f == 0) return launch_one<false, false, BM, BN, WM, WN, 0>(p, grid, stream);
+    return launch_one<false, false, BM, BN, WM, WN, -1>(p, grid, stream);
+  }
+  return launch_one<false, true, BM, BN, WM, WN, -1>(p, grid, stream);
 }
 
 }  // namespace
