@@ -507,12 +507,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
       HMMC_BAR();
       int n_item, n_split, n_tm, n_tn, n_kt, n_end;
       next_pos(n_item, n_split, n_tm, n_tn, n_kt, n_end);
-      if (kt + 1 >= kt_end) finish_item();
+      if (kt + 1 >= kt_end) {
+        // Item boundary: the leading group waits one barrier for the other group's last matrix segment, so both
+        // groups run their (VALU- and store-bound) epilogues TOGETHER and fill each other's issue bubbles, instead
+        // of one after the other with the matrix pipe idle both times; afterwards the wm = 1 group falls one
+        // barrier behind again.  Barrier counts stay equal: +1 per item for wm = 0, +1 per item but the last
+        // (and the one at kernel start) for wm = 1.
+        if (wm == 0) HMMC_BAR();
+        finish_item();
+        if (wm == 1 && n_item < nitems) HMMC_BAR();
+      }
       if (n_item >= nitems) break;
       item = n_item; split = n_split; tm = n_tm; tn = n_tn; kt = n_kt; kt_end = n_end;
       buf ^= 1;
     }
-    if (wm == 0) HMMC_BAR();
 #undef HMMC_BAR
 #undef HMMC_MM
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing out-of-range DMA must land before the LDS is released
