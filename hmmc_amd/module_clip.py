@@ -59,6 +59,7 @@ class Transformer(nn.Module):
         super().__init__()
         self.width, self.layers, self.heads = width, layers, heads
         self.causal = attn_mask is not None
+        self.ddp_layers_per_node = 3           # world_size > 1 only: granularity of gradient hand-over to DDP
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
 
     def flat_params(self):
@@ -72,7 +73,19 @@ class Transformer(nn.Module):
         if x.dtype != torch.float16:
             raise NotImplementedError("the HIP CLIP towers run the reference's as-written fp16 regime; "
                                       "model.float() (fp32-upcast) is not supported on this path")
-        return Fn.ClipTransformerFn.apply(x, nseq, L, self.heads, self.causal, *self.flat_params())
+        # One native call per direction on a single GPU.  Under data parallelism the tower is cut into runs of
+        # `ddp_layers_per_node` layers, one autograd node each, so that the gradients of the upper layers reach DDP's
+        # bucket hooks (and the xGMI all-reduce starts) while the lower layers are still in their backward pass.
+        per = self.layers
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            per = max(1, min(self.layers, int(self.ddp_layers_per_node)))
+        blocks = list(self.resblocks)
+        for i in range(0, self.layers, per):
+            params = []
+            for blk in blocks[i:i + per]:
+                params += Fn.block_params(blk)
+            x = Fn.ClipTransformerFn.apply(x, nseq, L, self.heads, self.causal, *params)
+        return x
 
 
 class VisualTransformer(nn.Module):

@@ -28,6 +28,9 @@ def _run(rank, world, store, out_dir):
     torch.cuda.set_device(0)
     model = BirdModel.from_pretrained("cross-base", state_dict=synth.finetune_state(synth.TINY),
                                       task_config=task_config(rank=rank)).cuda().train()
+    for m in model.modules():                  # exercise the per-run autograd nodes the towers use under DDP
+        if hasattr(m, "ddp_layers_per_node"):
+            m.ddp_layers_per_node = 1
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0]) if world > 1 else model
     B = 4
     b = B // world
