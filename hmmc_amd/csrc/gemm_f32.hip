@@ -52,6 +52,40 @@ __device__ __forceinline__ f4 load_op(const float* P, long sr, long sk, int R, i
   return v;
 }
 
+// Loop-invariant part of load_op: the thread's source pointer for K-step 0, its per-step advance, and whether its
+// 4 elements can be fetched as one aligned 16-byte load for every K-step that lies fully inside K (row / alignment
+// conditions do not depend on k).  Steps that reach past K go through load_op.
+struct OpLoader {
+  const float* ptr; long adv; bool vec4, any;
+};
+__device__ __forceinline__ OpLoader make_loader(const float* P, long sr, long sk, int R, int r0, int tid, bool vec) {
+  OpLoader L;
+  if (sk == 1) {
+    int r = r0 + (tid >> 2);
+    L.ptr = P + (long)r * sr + (tid & 3) * 4; L.adv = TK; L.any = r < R; L.vec4 = vec && L.any;
+  } else {
+    int r = r0 + (tid & 15) * 4;
+    L.ptr = P + (long)(tid >> 4) * sk + r; L.adv = (long)TK * sk; L.any = r < R; L.vec4 = vec && r + 3 < R;
+  }
+  return L;
+}
+__device__ __forceinline__ f4 load_inner(const OpLoader& L, long sk, int R, int r0, int kt, int tid) {
+  const float* p = L.ptr + (long)kt * L.adv;
+  if (L.vec4) return *reinterpret_cast<const f4*>(p);
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  if (L.any) {
+    if (sk == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = p[j];
+    } else {
+      int r = r0 + (tid & 15) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (r + j < R) v[j] = p[j];
+    }
+  }
+  return v;
+}
+
 // write them into the LDS image [k][row]
 __device__ __forceinline__ void store_op(float* S, f4 v, bool kcontig, int tid) {
   if (kcontig) {
@@ -80,18 +114,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
+  // Register-staged pipeline, PD K-steps deep: the global loads of step kt + PD are issued before step kt is computed and
+  // reach LDS one step before they are needed, so a lone workgroup on a CU (small M, or K-long weight gradients with
+  // few output tiles) still has PD loads in flight instead of waiting out one full memory latency per 16-deep K-step.
+  constexpr int PD = 3;
   const int nkt = (p.K + TK - 1) / TK;
-  f4 ra = load_op(p.A, p.sam, p.sak, p.M, p.K, m0, 0, tid, p.avec);
-  f4 rb = load_op(p.B, p.sbn, p.sbk, p.N, p.K, n0, 0, tid, p.bvec);
-  store_op(sA[0], ra, ak, tid);
-  store_op(sB[0], rb, bk, tid);
+  const int nfull = p.K / TK;                     // K-steps that lie fully inside K: no k bounds checks
+  const OpLoader LA = make_loader(p.A, p.sam, p.sak, p.M, m0, tid, p.avec);
+  const OpLoader LB = make_loader(p.B, p.sbn, p.sbk, p.N, n0, tid, p.bvec);
+  auto fetch_a = [&](int kt) { return kt < nfull ? load_inner(LA, p.sak, p.M, m0, kt, tid)
+                                                 : load_op(p.A, p.sam, p.sak, p.M, p.K, m0, kt * TK, tid, p.avec); };   // past K: zeros
+  auto fetch_b = [&](int kt) { return kt < nfull ? load_inner(LB, p.sbk, p.N, n0, kt, tid)
+                                                 : load_op(p.B, p.sbn, p.sbk, p.N, p.K, n0, kt * TK, tid, p.bvec); };
+  f4 ra[PD], rb[PD];
+#pragma unroll
+  for (int s = 0; s < PD; ++s) { ra[s] = fetch_a(s); rb[s] = fetch_b(s); }
+  store_op(sA[0], ra[0], ak, tid);
+  store_op(sB[0], rb[0], bk, tid);
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
+  auto step = [&](int kt, f4& ra_next, f4& rb_next, f4& ra_slot, f4& rb_slot) {
+    // ra_slot held step kt (already in LDS): refill it with step kt + PD; ra_next holds step kt + 1
     const int cur = kt & 1;
-    if (kt + 1 < nkt) {
-      ra = load_op(p.A, p.sam, p.sak, p.M, p.K, m0, (kt + 1) * TK, tid, p.avec);
-      rb = load_op(p.B, p.sbn, p.sbk, p.N, p.K, n0, (kt + 1) * TK, tid, p.bvec);
-    }
+    ra_slot = fetch_a(kt + PD);
+    rb_slot = fetch_b(kt + PD);
     const float* a = sA[cur];
     const float* b = sB[cur];
 #pragma unroll
@@ -108,10 +153,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nkt) {
-      store_op(sA[cur ^ 1], ra, ak, tid);
-      store_op(sB[cur ^ 1], rb, bk, tid);
+      store_op(sA[cur ^ 1], ra_next, ak, tid);
+      store_op(sB[cur ^ 1], rb_next, bk, tid);
     }
     __syncthreads();
+  };
+  for (int kt = 0; kt < nkt; kt += PD) {          // slots rotate with period PD: static register indices
+    step(kt, ra[1], rb[1], ra[0], rb[0]);
+    if (kt + 1 < nkt) step(kt + 1, ra[2], rb[2], ra[1], rb[1]);
+    if (kt + 2 < nkt) step(kt + 2, ra[0], rb[0], ra[2], rb[2]);
   }
   // lane owns C[m = .. + (lane & 15)][n = .. + 4*(lane >> 4) + r]
 #pragma unroll
