@@ -98,6 +98,23 @@ def test_gemm_random_and_epilogues():
     assert relerr(dh, dref) < 2e-3
 
 
+@pytest.mark.parametrize("b_kmajor", [True, False])
+def test_gemm_partial_last_round(b_kmajor):
+    """261 tiles of 256x256 on a 256-CU persistent grid (a last round of 5 tiles), ragged M, fused epilogues."""
+    M, N, K = 87 * 256 - 100, 768, 128
+    a = rnd(M, K, scale=0.5)
+    w = rnd(N, K, scale=0.1, seed=1) if b_kmajor else rnd(K, N, scale=0.1, seed=1)
+    bias, res = rnd(N, scale=0.1, seed=2), rnd(M, N, seed=3)
+    acc = a.float() @ (w.float().t() if b_kmajor else w.float())
+    c = ops.gemm_f16(a, w, M, N, K, b_kmajor=b_kmajor, bias=bias, resid=res, epilogue=ops.EPI_RESID)
+    ref = (res.float() + (acc + bias.float()).half().float()).half()
+    assert relerr(c, ref) < 1e-3 and float((c.float() - ref.float()).abs().max()) < 2e-2
+    assert relerr(c[-600:], ref[-600:]) < 1e-3
+    g, h = ops.gemm_f16(a, w, M, N, K, b_kmajor=b_kmajor, bias=bias, epilogue=ops.EPI_QGELU, want_aux=True)
+    assert relerr(h, (acc + bias.float()).half()) < 1e-3 and relerr(h[-600:], (acc + bias.float()).half()[-600:]) < 1e-3
+    assert relerr(g, h.float() * torch.sigmoid(1.702 * h.float())) < 2e-3
+
+
 @pytest.mark.parametrize("M,N,K,b_kmajor", [(1000, 384, 256, True), (4096, 768, 256, False), (2048 + 77, 512, 128, False)])
 def test_gemm_fused_column_sums(M, N, K, b_kmajor):
     """EPI_COLSUM: partial column sums of the fp16 values written (bias gradient without re-reading C)."""
