@@ -39,6 +39,7 @@ SIGNATURES = {
     "hmmc_l2norm_bwd": ("ppppiip", "i"),
     "hmmc_infonce_fwd": ("ppppiiffp", "i"),
     "hmmc_infonce_bwd": ("pppppiiffp", "i"),
+    "hmmc_retrieval_rank": ("pppiilip", "i"),
     "hmmc_topk_mean": ("pppiiiillp", "i"),
     "hmmc_temporal_pool_fwd": ("ppppiiip", "i"),
     "hmmc_temporal_pool_bwd": ("pppppiiip", "i"),

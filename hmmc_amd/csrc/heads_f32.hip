@@ -341,11 +341,37 @@ extern "C" int hmmc_infonce_bwd(const float* S, const float* lse_row, const floa
   return hmmc_launch_status();
 }
 
+// rank[q] = number of candidates scoring strictly higher than query q's target (metrics.py:12-20: position of the
+// diagonal in the descending sort, first position on ties).  One wave per query; transposed != 0 ranks the columns of S
+// (video -> text) without materialising S^T.
+__global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __restrict__ S, const int* __restrict__ target,
+                                                             int* __restrict__ rank, int Q, int V, long ld, int transposed) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  const int t = target ? target[q] : q;
+  const float ref = transposed ? S[(long)t * ld + q] : S[(long)q * ld + t];
+  float cnt = 0.f;
+  for (int j = lane; j < V; j += 64) {
+    float v = transposed ? S[(long)j * ld + q] : S[(long)q * ld + j];
+    cnt += v > ref ? 1.f : 0.f;
+  }
+  cnt = wave_sum(cnt);
+  if (lane == 0) rank[q] = (int)cnt;
+}
+
 extern "C" int hmmc_topk_mean(const float* S_frame, const float* base, float* out, int bq, int bv, int F, int k, long lds,
                               long ldb, hipStream_t stream) {
   if (!S_frame || !out || bq <= 0 || bv <= 0 || F <= 0 || F > 64 || k <= 0 || k > F) return HMMC_ERR_ARG;
   hipLaunchKernelGGL(topk_mean_kernel, dim3(nblk((long)bq * bv)), dim3(256), 0, stream, S_frame, base, out, bq, bv, F, k, lds,
                      ldb);
+  return hmmc_launch_status();
+}
+
+extern "C" int hmmc_retrieval_rank(const float* S, const int* target, int* rank, int Q, int V, long ld, int transposed,
+                                   hipStream_t stream) {
+  if (!S || !rank || Q <= 0 || V <= 0 || ld <= 0) return HMMC_ERR_ARG;
+  hipLaunchKernelGGL(retrieval_rank_kernel, dim3((Q + 3) / 4), dim3(256), 0, stream, S, target, rank, Q, V, ld, transposed);
   return hmmc_launch_status();
 }
 

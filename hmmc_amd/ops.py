@@ -293,6 +293,20 @@ def topk_mean(S_frame, bq, bv, F, k, base=None, lds=None, ldb=None):
     return out
 
 
+def retrieval_rank(sim, target=None, transposed=False):
+    """rank[q] = #{j : S(q, j) > S(q, target[q])} (int32); S(q, j) = sim[q, j], or sim[j, q] with transposed."""
+    _chk(sim, torch.float32, "sim")
+    assert sim.dim() == 2
+    R, C = sim.shape
+    Q, V = (C, R) if transposed else (R, C)
+    if target is not None:
+        _chk(target, torch.int32, "target")
+        assert target.numel() == Q
+    rank = torch.empty(Q, dtype=torch.int32, device=sim.device)
+    call("hmmc_retrieval_rank", ptr(sim), ptr(target), ptr(rank), Q, V, C, int(transposed))
+    return rank
+
+
 def temporal_pool_fwd(h, u, b, F, D):
     out = torch.empty((b, D), dtype=torch.float32, device=h.device)
     norms = torch.empty((b, F), dtype=torch.float32, device=h.device)

@@ -129,6 +129,13 @@ int hmmc_infonce_bwd(const float* S, const float* lse_row, const float* lse_col,
 int hmmc_topk_mean(const float* S_frame, const float* base, float* out, int bq, int bv, int F, int k, long lds, long ldb,
                    hmmc_stream_t stream);
 
+/* Rank metrics (metrics.py:12-39 compute_metrics): rank[q] = #{j : S(q, j) > S(q, target[q])}, i.e. the position of the
+ * ground-truth item in the descending sort of query q's scores (first position on ties); target NULL = the diagonal.
+ * S(q, j) = S[q*ld + j], or S[j*ld + q] with transposed != 0 (video -> text on the same matrix).  R@K, median and mean
+ * rank follow from the Q integers on the host, as in the reference. */
+int hmmc_retrieval_rank(const float* S, const int* target, int* rank, int Q, int V, long ld, int transposed,
+                        hmmc_stream_t stream);
+
 /* video_emb[b] = mean_f (h + u)/||h + u||  (modules/module_cross.py:207-212); u may be NULL (use_temp False). */
 int hmmc_temporal_pool_fwd(const float* h, const float* u, float* out, float* norms, int b, int F, int D,
                            hmmc_stream_t stream);

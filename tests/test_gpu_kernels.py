@@ -2,6 +2,8 @@
 fp32 reference of the same op (bit-exact on integer-valued data where the op is exact)."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -246,3 +248,19 @@ def test_attention_fwd_bwd(nseq, L, H, causal):
         assert torch.equal(dqkv, dqkv2)
         ref = dqkv.float().view(nseq, L, 3 * D).sum(1)
         assert float((part - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-4
+
+
+def test_retrieval_rank_ties_and_targets():
+    """metrics.py:20-28: the rank is the first position of the target's score in the descending sort."""
+    torch.manual_seed(3)
+    S = torch.randint(-4, 5, (37, 53), device=DEV).float()            # many exact ties
+    tgt = torch.randint(0, 53, (37,), device=DEV, dtype=torch.int32)
+    got = ops.retrieval_rank(S, target=tgt).cpu()
+    ref = (S > S.gather(1, tgt.long()[:, None])).sum(1).cpu()
+    assert torch.equal(got.long(), ref)
+    sq = S[:, :37].contiguous()
+    sx = np.sort(-sq.cpu().numpy(), axis=1)
+    d = np.diag(-sq.cpu().numpy())[:, None]
+    first = np.array([np.where(sx[i] == d[i])[0][0] for i in range(37)])
+    assert np.array_equal(ops.retrieval_rank(sq).cpu().numpy(), first)
+    assert np.array_equal(ops.retrieval_rank(sq, transposed=True).cpu().numpy(), ops.retrieval_rank(sq.t().contiguous()).cpu().numpy())

@@ -108,6 +108,12 @@ def test_eval_scorer_ranks_identical():
             assert np.array_equal(got_rank, ref_rank), f"retrieval ranks differ at k={k}"
             m = O.compute_metrics((sv + fk).cpu().numpy())
             close([m["R1"], m["R5"], m["R10"], m["MR"], m["MeanR"]], g[f"metrics{k}"], 1e-9, what="metrics")
+            from hmmc_amd import metrics as M      # rank metrics with the ranking on the device
+            md, mvt = M.compute_metrics_t2v_v2t(sv + fk)
+            close([md["R1"], md["R5"], md["R10"], md["MR"], md["MeanR"]], g[f"metrics{k}"], 1e-9, what="device metrics")
+            assert np.array_equal(M.ranks(sv + fk), m["ranks"])
+            mo = O.compute_metrics((sv + fk).cpu().numpy().T)
+            assert np.array_equal(M.ranks(sv + fk, transposed=True), mo["ranks"]) and mvt["R1"] == mo["R1"]
 
 
 def test_temporal_fn_vs_oracle():
