@@ -44,7 +44,8 @@ class VitEmbedFn(torch.autograd.Function):
         n = video4d.shape[0]
         D, _, p, _ = conv_w.shape
         L = pos.shape[0]
-        patches = ops.patchify(video4d, p)                                   # [n*L, 3pp] fp16, class rows zero
+        # [n*L, 3pp] fp16, class rows zero; uint8 frames are normalised on the fly (CLIP mean / std)
+        patches = ops.patchify_u8(video4d, p) if video4d.dtype == torch.uint8 else ops.patchify(video4d, p)
         x0 = ops.gemm_f16(patches, conv_w.view(D, -1), n * L, D, 3 * p * p)
         ops.vit_embed_(x0, cls, pos, L)
         x, mean, rstd = ops.layernorm_fwd(x0, ln_w, ln_b, 1e-5)

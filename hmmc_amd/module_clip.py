@@ -117,7 +117,8 @@ class VisualTransformer(nn.Module):
 
     def hidden_tokens(self, x):
         n = x.shape[0]
-        x = x.float().contiguous()          # the kernel casts fp32 pixels to fp16 while patchifying (image.type(fp16))
+        # the kernel casts fp32 pixels to fp16 while patchifying (image.type(fp16)); raw uint8 frames are normalised there too
+        x = x.contiguous() if x.dtype == torch.uint8 else x.float().contiguous()
         t = Fn.VitEmbedFn.apply(x, self.conv1.weight, self.class_embedding, self.positional_embedding,
                                 self.ln_pre.weight, self.ln_pre.bias)
         return self.transformer(t, n, self.tokens)

@@ -152,6 +152,23 @@ def patchify(video4d, patch):
     return out
 
 
+CLIP_PIXEL_MEAN = (0.48145466, 0.4578275, 0.40821073)      # dataloaders/rawvideo_util.py / dataloader_*: Normalize(...)
+CLIP_PIXEL_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def patchify_u8(video4d_u8, patch, mean=CLIP_PIXEL_MEAN, std=CLIP_PIXEL_STD):
+    """uint8 [n,3,H,W] -> fp16 patches as patchify(), with x/255 and the per-channel normalisation fused in."""
+    import ctypes
+    _chk(video4d_u8, torch.uint8, "video")
+    n, c, H, W = video4d_u8.shape
+    assert c == 3
+    g = H // patch
+    out = torch.empty((n * (g * g + 1), 3 * patch * patch), dtype=torch.float16, device=video4d_u8.device)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    call("hmmc_patchify_u8", ptr(video4d_u8), ptr(out), n, H, W, patch, m3, s3)
+    return out
+
+
 def vit_embed_(x, cls, pos, L):
     _chk(x, torch.float16, "x")
     _chk(cls, torch.float32, "cls")

@@ -81,6 +81,10 @@ int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int in_dtype, i
 /* Patch extraction for conv1 (kernel = stride = patch, modules/module_clip.py:278,307-310):
  * fp32 NCHW frames -> fp16 [nframes*(g*g+1), 3*patch*patch]; row 0 of each frame is zero (class slot). */
 int hmmc_patchify(const float* img, void* out, int nframes, int H, int W, int patch, hmmc_stream_t stream);
+/* The same from uint8 NCHW frames with the loader's normalisation fused in (dataloaders/dataloader_msrvtt_retrieval.py:
+ * 242-247: x/255, (x - mean[c]) / std[c] in fp32, then fp16): a quarter of the input bytes.  mean3 / std3 are HOST arrays. */
+int hmmc_patchify_u8(const void* img, void* out, int nframes, int H, int W, int patch, const float* mean3,
+                     const float* std3, hmmc_stream_t stream);
 /* In place on the patch-GEMM output: class_embedding into row 0, + positional_embedding
  * (modules/module_clip.py:311-312), with the reference's fp16 rounding points. */
 int hmmc_vit_embed(void* x, const float* cls, const float* pos, long rows, int L, int D, hmmc_stream_t stream);

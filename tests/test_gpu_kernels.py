@@ -264,3 +264,16 @@ def test_retrieval_rank_ties_and_targets():
     first = np.array([np.where(sx[i] == d[i])[0][0] for i in range(37)])
     assert np.array_equal(ops.retrieval_rank(sq).cpu().numpy(), first)
     assert np.array_equal(ops.retrieval_rank(sq, transposed=True).cpu().numpy(), ops.retrieval_rank(sq.t().contiguous()).cpu().numpy())
+
+
+def test_patchify_u8_matches_loader_normalisation():
+    """uint8 frames + fused ToTensor / Normalize (dataloader_msrvtt_retrieval.py:242-247) == patchify of the fp32 frames."""
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (5, 3, 224, 224), generator=g, dtype=torch.uint8)
+    mean = torch.tensor(ops.CLIP_PIXEL_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(ops.CLIP_PIXEL_STD).view(1, 3, 1, 1)
+    f32 = (u8.float().div(255.0) - mean) / std
+    for patch in (32, 16):
+        a = ops.patchify_u8(u8.to(DEV), patch)
+        b = ops.patchify(f32.to(DEV).contiguous(), patch)
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())

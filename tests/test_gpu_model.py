@@ -299,3 +299,25 @@ def test_train_steps_vs_reference_golden():
                 ref = torch.from_numpy(g[f"p{step}:{k}"]) - init[k]
                 cos.append(float(torch.dot(mine, ref) / (mine.norm() * ref.norm() + 1e-12)))
             assert np.mean(cos) > 0.6, f"step {step}: weight movement disagrees with the reference: {cos}"
+
+
+def test_uint8_frames_equal_normalised_fp32_frames():
+    """raw uint8 frames with the loader's normalisation fused into the patch extraction give the
+    same loss and gradients as the fp32 frames the reference's loader hands over."""
+    from hmmc_amd.modeling import BirdModel
+    from hmmc_amd import ops as _ops
+    sd = synth.finetune_state(synth.TINY)
+    ids, mask, vid, vf, idx = synth.finetune_batch(4, 4, 32, tag="u8")
+    g = torch.Generator().manual_seed(11)
+    u8 = torch.randint(0, 256, vid.shape, generator=g, dtype=torch.uint8)
+    mean = torch.tensor(_ops.CLIP_PIXEL_MEAN).view(1, 1, 3, 1, 1)
+    std = torch.tensor(_ops.CLIP_PIXEL_STD).view(1, 1, 3, 1, 1)
+    f32 = (u8.float().div(255.0) - mean) / std
+    out = []
+    for video in (u8, f32):
+        model = BirdModel.from_pretrained("cross-base", state_dict=sd, task_config=task_config(max_frames=4)).to(DEV).train()
+        loss = model(ids.to(DEV), mask.to(DEV), video.to(DEV), vf.to(DEV), idx.to(DEV), 1)
+        loss.backward()
+        out.append((float(loss), model.visual_encoder.visual.conv1.weight.grad.clone()))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
