@@ -360,7 +360,25 @@ def fx_moco(mclip, mmodel, mopt, mmetrics):
         save(f"moco_{mode}", **out)
 
 
-FIXTURES = {"head": fx_head, "enc_tiny": fx_enc_tiny, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
+def fx_manifest(mclip, mmodel, mopt, mmetrics):
+    """state_dict layout (key -> shape, dtype) of the reference models as written (fp16 CLIP weights): what a
+    pytorch_model.bin.N checkpoint of the reference holds (main_task_retrieval.py:215-222)."""
+    out = {}
+    for tag, cls, dims, sd, tc in (
+            ("finetune_tiny", mmodel.BirdModel, synth.TINY, synth.finetune_state(synth.TINY), {}),
+            ("finetune_b32", mmodel.BirdModel, synth.VIT_B32, synth.finetune_state(synth.VIT_B32), {"max_frames": 12}),
+            ("pretrain_tiny", mmodel.BirdPreTrainedModel, synth.TINY, synth.pretrain_state(synth.TINY, 16, 4),
+             {"dataset": "chvtt", "contrast_num_negative": 16})):
+        model, _ = build_reference_model(mclip, cls, dims, sd, "aswritten", **tc)
+        out[tag] = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()}
+        out[tag + ":trainable"] = sorted(n for n, p in model.named_parameters() if p.requires_grad)
+    path = os.path.join(HERE, "statedict_manifest.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+FIXTURES = {"manifest": fx_manifest, "head": fx_head, "enc_tiny": fx_enc_tiny, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
             "bertadam": fx_bertadam, "train_ft": fx_train_ft, "moco": fx_moco}
 
 
