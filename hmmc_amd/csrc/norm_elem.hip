@@ -195,18 +195,20 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 }
 
 // LayerNorm backward second stage: columns [0,D) -> dgamma, [D,2D) -> dbeta (fp32), [2D,3D) -> dx_colsum (fp16 or fp32)
-__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, void* __restrict__ dxsum, int dx_dtype,
-                                                        int R, int N, int D) {
-  __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void ln_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, void* __restrict__ dxsum, int dx_dtype,
+                                                         int R, int N, int D) {
+  // 32 columns x 32 row-lanes: only N / 32 blocks exist (72 for 3 x 768 columns), so each carries 16 waves to keep
+  // enough 128-byte row segments in flight; the row-lanes are combined in fixed order (deterministic)
+  __shared__ float red[32][33];
   const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + c;
   float a0 = 0.f, a1 = 0.f;
   if (col < N) {
     int r = rl;
-    for (; r + 8 < R; r += 16) {
+    for (; r + 32 < R; r += 64) {
       a0 += partial[(long)r * N + col];
-      a1 += partial[(long)(r + 8) * N + col];
+      a1 += partial[(long)(r + 32) * N + col];
     }
     if (r < R) a0 += partial[(long)r * N + col];
   }
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
   if (rl == 0 && col < N) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][c];
+    for (int k = 0; k < 32; ++k) t += red[k][c];
     if (col < D) dgamma[col] = t;
     else if (col < 2 * D) dbeta[col - D] = t;
     else if (dx_dtype == 0) reinterpret_cast<half_t*>(dxsum)[col - 2 * D] = (half_t)t;
@@ -448,7 +450,7 @@ extern "C" int hmmc_layernorm_bwd(const void* dy, const void* x, const float* ga
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)dy, (const float*)x, gamma, mean,
                        rstd, (const float*)dres, (float*)dx, partial, row_index, rows, D, in_stride, dx_colsum != nullptr);
   // one reduce over the np*D partial columns: [0,D) dgamma, [D,2D) dbeta (fp32), [2D,3D) dx_colsum (dtype of dx)
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3((np * D + 31) / 32), dim3(256), 0, stream, (const float*)partial, dgamma, dbeta,
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3((np * D + 31) / 32), dim3(1024), 0, stream, (const float*)partial, dgamma, dbeta,
                      dx_colsum, dtype, nb, np * D, D);
   return hmmc_launch_status();
 }
