@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import logging
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -349,8 +350,22 @@ class BirdModel(BirdPreTrainedModel):
         video = torch.as_tensor(video_data)
         if not self.training:
             return None
-        query_output = self.text_encoder(query_ids, query_mask)
-        visual_output, frame_output = self.visual_encoder(video, video_frame)
+        if _OVERLAP_TOWERS and video.is_cuda:
+            # The text tower (small, latency-bound kernels) runs on a side stream beside the frame tower, whose
+            # persistent GEMMs leave most CUs idle in their last, partial round.  Autograd replays each node's backward
+            # on its forward stream, so the two backward passes overlap the same way.
+            cur = torch.cuda.current_stream(video.device)
+            side = _side_stream(video.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                query_output = self.text_encoder(query_ids, query_mask)
+            visual_output, frame_output = self.visual_encoder(video, video_frame)
+            cur.wait_stream(side)
+            query_output.record_stream(cur)
+            query_ids.record_stream(side)
+        else:
+            query_output = self.text_encoder(query_ids, query_mask)
+            visual_output, frame_output = self.visual_encoder(video, video_frame)
         b, F, E = frame_output.shape
         # one packed all-gather [b, (F+2)*E] instead of the reference's three (modules/modeling.py:698-700)
         packed = dist_collect(torch.cat([visual_output, query_output, frame_output.reshape(b, F * E)], dim=1))
@@ -363,6 +378,17 @@ class BirdModel(BirdPreTrainedModel):
         if self.task_config.local_rank == 0 and getattr(self.task_config, "logdir", None):
             self.task_config.writer.add_scalar("loss", float(loss), global_step=global_step)
         return loss
+
+
+_OVERLAP_TOWERS = os.environ.get("HMMC_OVERLAP_TOWERS", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 class MLP(nn.Module):

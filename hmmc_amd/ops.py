@@ -34,8 +34,9 @@ def gemm_profile_stop():
 
 
 def workspace(nbytes, device, tag="default"):
-    """Grow-only scratch buffer per (device, tag); kernels never allocate."""
-    key = (str(device), tag)
+    """Grow-only scratch buffer per (device, stream, tag); kernels never allocate.  Keyed by stream because the two
+    encoder towers may run on different streams at the same time."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
