@@ -70,7 +70,7 @@ SIGNATURES = {
     "hmmc_tower_bwd_scratch_bytes": ("lii", "z"),
     "hmmc_tower_workspace_bytes": ("liii", "z"),
     "hmmc_tower_fwd": ("ppppiiiiiiifipzp", "i"),
-    "hmmc_tower_bwd": ("pppppppiiiiiiipzp", "i"),
+    "hmmc_tower_bwd": ("pppppppiiiiiiipzpp", "i"),
 }
 
 ERRORS = {-1: "invalid argument", -2: "unsupported shape/alignment", -3: "workspace too small", -4: "kernel launch failed"}

@@ -131,9 +131,22 @@ static size_t general_bytes(long tokens, int D, int fp32) {
   return al(w);
 }
 
-// [general: LayerNorm / column-sum / split-K slabs][fp16 tower: bias-gradient partials]
+static size_t wgrad_ws_bytes(long tokens, int D, int fp32) {
+  if (fp32) return 0;
+  size_t g = hmmc_gemm_f16_workspace(3 * D, D, (int)tokens);
+  size_t g2 = hmmc_gemm_f16_workspace(4 * D, D, (int)tokens);
+  size_t g3 = hmmc_gemm_f16_workspace(D, 4 * D, (int)tokens);
+  size_t g4 = hmmc_gemm_f16_workspace(D, D, (int)tokens);
+  if (g2 > g) g = g2;
+  if (g3 > g) g = g3;
+  if (g4 > g) g = g4;
+  return al(g);
+}
+
+// [general: LayerNorm / column-sum / split-K slabs][fp16 tower: bias-gradient partials][split-K slabs of the
+// weight-gradient stream]
 extern "C" size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32) {
-  return general_bytes(tokens, D, fp32) + (fp32 ? 0 : partial_bytes(tokens, D, nseq));
+  return general_bytes(tokens, D, fp32) + (fp32 ? 0 : partial_bytes(tokens, D, nseq)) + wgrad_ws_bytes(tokens, D, fp32);
 }
 
 // y = tower(x).  keep_acts: acts holds nlayers slabs (training); otherwise one slab is reused (key encoders, eval).
@@ -170,9 +183,31 @@ extern "C" int hmmc_tower_fwd(const void* x, void* y, const void* const* params,
 }
 
 // dx = d tower / d x (dy given), grads[nlayers*12] written.  x0 is the tower input given to hmmc_tower_fwd.
+namespace {
+// events of one backward call: main -> weight-gradient stream ("operand ready") and back ("operand no longer read")
+struct WgradSync {
+  hipEvent_t ready = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool done_set[4] = {false, false, false, false};
+  bool ok = false;
+  explicit WgradSync(bool two) {
+    if (!two) return;
+    ok = hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 4; ++k) ok = ok && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
+  }
+  ~WgradSync() {
+    if (ready) (void)hipEventDestroy(ready);
+    for (int k = 0; k < 4; ++k) if (done[k]) (void)hipEventDestroy(done[k]);
+  }
+};
+}  // namespace
+
+// wgrad_stream (optional): the four weight-gradient GEMMs of every layer are leaves of the backward pass; given a second
+// stream they run there, beside the dgrad / LayerNorm / attention chain on `s`, and fill the CUs the persistent GEMMs of
+// that chain leave idle in their partial last rounds.  `s` waits for the stream before this call returns control of the
+// gradients (stream order), so the caller sees ordinary single-stream semantics.
 extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads,
                               const void* acts, void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal,
-                              int fp32, void* workspace, size_t ws_bytes, hipStream_t s) {
+                              int fp32, void* workspace, size_t ws_bytes, hipStream_t wgrad_stream, hipStream_t s) {
   if (!dy || !dx || !x0 || !params || !grads || !acts || !scratch || nseq <= 0 || L <= 0 || nlayers <= 0 || D != heads * 64)
     return HMMC_ERR_ARG;
   const bool f32 = fp32 != 0;
@@ -192,8 +227,31 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
   // in_proj) instead of re-reading them.  Only the c_proj bias of the LAST layer still needs its own pass over dy.
   const size_t gen = general_bytes(T, D, fp32);
   const size_t part_bytes = f32 ? 0 : partial_bytes(T, D, nseq);
-  if (ws_bytes < gen + part_bytes) return HMMC_ERR_WORKSPACE;
+  const size_t wws_bytes = wgrad_ws_bytes(T, D, fp32);
+  if (ws_bytes < gen + part_bytes + wws_bytes) return HMMC_ERR_WORKSPACE;
   float* part = f32 ? nullptr : (float*)((char*)workspace + gen);
+  void* wws = (char*)workspace + gen + part_bytes;
+  hipStream_t sw = wgrad_stream ? wgrad_stream : s;
+  const bool two = sw != s;
+  WgradSync sync(two);
+  if (two && !sync.ok) return HMMC_ERR_LAUNCH;
+  // weight gradient k of a layer (0: c_proj <- g_in, 1: c_fc <- dh, 2: out_proj <- dx1, 3: in_proj <- dqkv)
+  auto side_wgrad = [&](int k, const void* dyk, const void* xk, void* dW, int Np, int Kp) -> int {
+    if (two) {
+      if (hipEventRecord(sync.ready, s) != hipSuccess || hipStreamWaitEvent(sw, sync.ready, 0) != hipSuccess) return HMMC_ERR_LAUNCH;
+    }
+    int rc = wgrad(f32, dyk, xk, dW, (int)T, Np, Kp, two ? wws : workspace, two ? wws_bytes : gen, sw);
+    if (rc == 0 && two) {
+      if (hipEventRecord(sync.done[k], sw) != hipSuccess) return HMMC_ERR_LAUNCH;
+      sync.done_set[k] = true;
+    }
+    return rc;
+  };
+  // the chain on `s` is about to overwrite the operand weight gradient k read (scratch buffers are reused every layer)
+  auto before_overwrite = [&](int k) -> int {
+    if (two && sync.done_set[k] && hipStreamWaitEvent(s, sync.done[k], 0) != hipSuccess) return HMMC_ERR_LAUNCH;
+    return 0;
+  };
   const void* g_in = dy;
   CK(hmmc_colsum(dy, grads[(size_t)(nlayers - 1) * 12 + 11], (int)T, D, D, dt, dt, 0, workspace, gen, s));
   for (int i = nlayers - 1; i >= 0; --i) {
@@ -203,7 +261,8 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
     const void* xin = i == 0 ? x0 : (const void*)a.x;
     void* g_out = i == 0 ? dx : ping[i & 1];
     // MLP: x2 = x1 + c_proj(QuickGELU(c_fc(ln2)))
-    CK(wgrad(f32, g_in, a.g, G[10], (int)T, D, 4 * D, workspace, gen, s));
+    CK(side_wgrad(0, g_in, a.g, G[10], D, 4 * D));
+    CK(before_overwrite(1));
     if (f32) {
       CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_DGELU, s));
       CK(hmmc_colsum(dh, G[9], (int)T, 4 * D, 4 * D, dt, dt, 0, workspace, gen, s));
@@ -212,13 +271,15 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
       CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_DGELU, s, part, part_bytes));
       CK(hmmc_colsum(part, G[9], rows, 4 * D, 4 * D, 1, dt, 0, workspace, gen, s));
     }
-    CK(wgrad(f32, dh, a.ln2, G[8], (int)T, 4 * D, D, workspace, gen, s));
+    CK(side_wgrad(1, dh, a.ln2, G[8], 4 * D, D));
     CK(dgrad(f32, dh, P[8], dln, (int)T, 4 * D, D, nullptr, 0, s));
+    CK(before_overwrite(2));
     CK(hmmc_layernorm_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], G[5], nullptr,
                           (int)T, D, D, dt, workspace, gen, s));               // G[5]: out_proj bias = colsum(dx1)
     // attention: x1 = x + out_proj(attn(in_proj(ln1)))
-    CK(wgrad(f32, dx1, a.att, G[4], (int)T, D, D, workspace, gen, s));
+    CK(side_wgrad(2, dx1, a.att, G[4], D, D));
     CK(dgrad(f32, dx1, P[4], dln, (int)T, D, D, nullptr, 0, s));                 // datt (reuses dln)
+    CK(before_overwrite(3));
     if (f32) {
       CK(hmmc_temporal_attention_bwd((const float*)a.qkv, a.stat, (const float*)dln, (float*)dqkv, nseq, L, heads, s));
       CK(hmmc_colsum(dqkv, G[3], (int)T, 3 * D, 3 * D, dt, dt, 0, workspace, gen, s));
@@ -229,12 +290,17 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
       CK(hmmc_attention_f16_bwd(a.qkv, a.att, a.stat, dln, dqkv, nullptr, nseq, L, heads, causal, s));
       CK(hmmc_colsum(dqkv, G[3], (int)T, 3 * D, 3 * D, dt, dt, 0, workspace, gen, s));
     }
-    CK(wgrad(f32, dqkv, a.ln1, G[2], (int)T, 3 * D, D, workspace, gen, s));
+    CK(side_wgrad(3, dqkv, a.ln1, G[2], 3 * D, D));
     CK(dgrad(f32, dqkv, P[2], dln, (int)T, 3 * D, D, nullptr, 0, s));
-    // the c_proj bias gradient of the layer below is the column sum of the dx this call writes
+    // the c_proj bias gradient of the layer below is the column sum of the dx this call writes (into the buffer weight
+    // gradient 0 of the layer above read as its g_in)
+    CK(before_overwrite(0));
     CK(hmmc_layernorm_bwd(dln, xin, (const float*)P[0], a.m1, a.r1, dx1, g_out, (float*)G[0], (float*)G[1],
                           i > 0 ? grads[(size_t)(i - 1) * 12 + 11] : nullptr, nullptr, (int)T, D, D, dt, workspace, gen, s));
     g_in = g_out;
+  }
+  if (two) {                                     // hand the weight gradients back in `s` order
+    if (hipEventRecord(sync.ready, sw) != hipSuccess || hipStreamWaitEvent(s, sync.ready, 0) != hipSuccess) return HMMC_ERR_LAUNCH;
   }
   return HMMC_OK;
 }

@@ -103,6 +103,9 @@ def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep):
     return y, (acts if keep else None)
 
 
+_WGRAD_STREAM = __import__("os").environ.get("HMMC_WGRAD_STREAM", "1") != "0"
+
+
 def _tower_backward(dy, x0, params, acts, nseq, L, heads, causal, fp32):
     from ._lib import call, ptr, query
     T, D = x0.shape
@@ -112,8 +115,10 @@ def _tower_backward(dy, x0, params, acts, nseq, L, heads, causal, fp32):
     wsb = query("hmmc_tower_workspace_bytes", T, D, nseq, int(fp32))
     ws = ops.workspace(wsb, x0.device, "tower")
     dx = torch.empty_like(x0)
+    # weight gradients on their own stream (leaves of the backward): the library orders the two streams itself
+    wst = ops.aux_stream(x0.device, "wgrad").cuda_stream if _WGRAD_STREAM else None
     call("hmmc_tower_bwd", ptr(dy), ptr(dx), ptr(x0), _ptr_array(params), _ptr_array(grads), ptr(acts), ptr(scratch), nseq, L,
-         heads, D, nl, int(causal), int(fp32), ptr(ws), wsb)
+         heads, D, nl, int(causal), int(fp32), ptr(ws), wsb, wst)
     return dx, grads
 
 

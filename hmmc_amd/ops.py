@@ -44,6 +44,19 @@ def workspace(nbytes, device, tag="default"):
     return buf
 
 
+_aux_streams = {}
+
+
+def aux_stream(device, tag):
+    """A helper stream tied to (device, current stream, tag): e.g. the weight-gradient stream of a tower backward."""
+    cur = torch.cuda.current_stream(device)
+    key = (str(device), cur.cuda_stream, tag)
+    st = _aux_streams.get(key)
+    if st is None:
+        st = _aux_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _chk(t, dtype, name):
     if t.dtype != dtype or not t.is_cuda:
         raise TypeError(f"{name}: expected cuda {dtype}, got {t.device} {t.dtype}")

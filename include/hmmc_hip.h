@@ -218,9 +218,12 @@ size_t hmmc_tower_bwd_scratch_bytes(long tokens, int D, int fp32);
 size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32);
 int hmmc_tower_fwd(const void* x, void* y, const void* const* params, void* acts, int keep_acts, int nseq, int L, int heads,
                    int D, int nlayers, int causal, float eps, int fp32, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+/* wgrad_stream (optional, NULL = `stream`): a second stream for the weight-gradient GEMMs, which are leaves of the backward
+ * pass; they then run beside the dgrad / LayerNorm / attention chain.  `stream` waits for it before the call's work is
+ * complete in stream order, so callers keep single-stream semantics. */
 int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads, const void* acts,
                    void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal, int fp32, void* workspace,
-                   size_t ws_bytes, hmmc_stream_t stream);
+                   size_t ws_bytes, hmmc_stream_t wgrad_stream, hmmc_stream_t stream);
 
 #ifdef __cplusplus
 }
