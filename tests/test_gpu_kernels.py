@@ -277,3 +277,28 @@ def test_patchify_u8_matches_loader_normalisation():
         a = ops.patchify_u8(u8.to(DEV), patch)
         b = ops.patchify(f32.to(DEV).contiguous(), patch)
         assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+
+
+def test_error_statuses_instead_of_faults():
+    """Shapes the kernels cannot take come back as HMMC_ERR_* (RuntimeError in the host layer), never as a launch."""
+    from hmmc_amd._lib import call, ptr, query
+    a = rnd(64, 72)                                    # K = 72: not a multiple of the 64-deep K-tile of a k-major operand
+    w = rnd(64, 72, seed=1)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        ops.gemm_f16(a, w, 64, 64, 72)
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        call("hmmc_gemm_f16", ptr(a), None, ptr(a), 64, 64, 64, 72, 72, 64, 1, 1, None, None, None, None, 0, None, 0)
+    qkv = rnd(300 * 2, 3 * 64)
+    with pytest.raises(RuntimeError, match="unsupported"):          # sequences longer than 256 tokens do not occur on the path
+        ops.attention_f16_fwd(qkv, 2, 300, 1, False)
+    x = rnd(128, 768)
+    g = torch.ones(768, device=DEV)
+    y, mean, rstd = ops.layernorm_fwd(x, g, torch.zeros(768, device=DEV), 1e-5)
+    dx = torch.empty_like(x)
+    dg, db = torch.empty(768, device=DEV), torch.empty(768, device=DEV)
+    small = torch.empty(16, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError, match="workspace"):
+        call("hmmc_layernorm_bwd", ptr(x), ptr(x), ptr(g), ptr(mean), ptr(rstd), None, ptr(dx), ptr(dg), ptr(db), None, None,
+             128, 768, 768, 0, ptr(small), 16)
+    with pytest.raises(TypeError):
+        ops.gemm_f16(a.cpu(), w, 64, 64, 72)                        # host tensors are rejected: there is no CPU path
