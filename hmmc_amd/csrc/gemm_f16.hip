@@ -150,9 +150,16 @@ __device__ __forceinline__ void swap_rows(unsigned& x, unsigned& y) {
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ u4 join(h4 a, h4 b) {
-  u2 x = __builtin_bit_cast(u2, a), y = __builtin_bit_cast(u2, b);
-  return u4{x[0], x[1], y[0], y[1]};
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> one dword of two fp16 (round to nearest even): v_cvt_pk_f16_f32
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, h2v));
+}
+// the MFMA-layout values of tiles 2q and 2q+1 of one strip (fp32, still to be rounded) -> the 16-byte piece
+__device__ __forceinline__ u4 pack_pair(const f4& t0, const f4& t1) {
+  return u4{pk2(t0[0], t0[1]), pk2(t0[2], t0[3]), pk2(t1[0], t1[1]), pk2(t1[2], t1[3])};
 }
 // piece of tile 2q and piece of tile 2q+1 (MFMA layout)  <->  8 consecutive columns of the lane's row
 __device__ __forceinline__ void swap_pair(u4& v) {
@@ -165,34 +172,37 @@ __device__ __forceinline__ void swap_pair(u4& v) {
 // row_ror:8 reads lane c ^ 8 of the same 16-lane row; the bank mask picks which half of the row is written:
 // lanes c >= 8 take the neighbour's y into x, lanes c < 8 the neighbour's x into y.
 __device__ __forceinline__ void to_store_order(u4& x, u4& y) {
-  u4 nx, ny;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    nx[e] = (unsigned)__builtin_amdgcn_update_dpp((int)x[e], (int)y[e], 0x128, 0xf, 0xc, false);
-    ny[e] = (unsigned)__builtin_amdgcn_update_dpp((int)y[e], (int)x[e], 0x128, 0xf, 0x3, false);
+    const unsigned x0 = x[e];
+    x[e] = (unsigned)__builtin_amdgcn_update_dpp((int)x[e], (int)y[e], 0x128, 0xf, 0xc, false);
+    y[e] = (unsigned)__builtin_amdgcn_update_dpp((int)y[e], (int)x0, 0x128, 0xf, 0x3, false);
   }
-  x = nx; y = ny;
+}
+__device__ __forceinline__ f4 unpack2(unsigned lo, unsigned hi) {
+  h2v a = __builtin_bit_cast(h2v, lo), b = __builtin_bit_cast(h2v, hi);
+  return f4{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
 }
 
-// F >= 0: the epilogue flags at compile time; F < 0: p.flags at run time
-template <int MT, int F>
-__device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
+// F >= 0: the epilogue flags at compile time; F < 0: p.flags at run time.  FULL: interior tile, no masks anywhere.
+template <int MT, int F, bool FULL>
+__device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
   const int flags = F >= 0 ? (F & ~EPI_COLSUM) : (p.flags & ~EPI_COLSUM);
   const bool want_csum = F >= 0 ? (F & EPI_COLSUM) != 0 : p.csum != nullptr;
   const int c = lane & 15, g = lane >> 4;
   const int n_l = 32 * (c >> 3) + 16 * (g & 1) + 8 * (g >> 1);   // this lane's 8 columns within the wave's 64
-  const bool n_ok = n0 + n_l < p.N;                              // N % 8 == 0: a 16-byte piece is all-in or all-out
+  const bool n_ok = FULL || n0 + n_l < p.N;                      // N % 8 == 0: a 16-byte piece is all-in or all-out
   const int r_l = c & 7;                                         // this lane's row within a group of 8
-  const bool full = m_base + 16 * MT <= p.M && n0 + 64 <= p.N;   // wave-uniform: no masks on interior tiles
   // global address = uniform 64-bit base (scalar registers) + 32-bit lane offset
   const unsigned voff = ((unsigned)r_l * (unsigned)p.ldc + (unsigned)n_l) * 2u;
   const size_t row8 = (size_t)p.ldc * 16u;                       // bytes between row r and row r + 8
-  h4 bias[4];
+  f4 bias[4];
   if (flags & EPI_BIAS) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int n = n0 + 16 * j + 4 * g;
-      bias[j] = *reinterpret_cast<const h4*>(p.bias + (n < p.N ? n : 0));
+      h4 bv = *reinterpret_cast<const h4*>(p.bias + ((FULL || n < p.N) ? n : 0));
+      bias[j] = f4{(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
     }
   }
   const bool has_src = flags & (EPI_DGELU | EPI_RESID);
@@ -205,7 +215,7 @@ __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4
   for (int j = 0; j < 4; ++j) csum[j] = f4{0.f, 0.f, 0.f, 0.f};
   auto store2 = [&](half_t* dst, int i, u4 o0, u4 o1) {
     char* sb = reinterpret_cast<char*>(dst) + ((size_t)(m_base + 16 * i) * p.ldc + n0) * 2u;
-    if (full) {
+    if (FULL) {
       *reinterpret_cast<u4*>(sb + voff) = o0;
       *reinterpret_cast<u4*>(sb + row8 + voff) = o1;
     } else {
@@ -216,13 +226,13 @@ __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4
   };
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    h4 in[4];
+    f4 in[4];
     if (has_src) {
       if (i % HB == 0) {
 #pragma unroll
         for (int ii = 0; ii < HB; ++ii) {
           const char* sb = src + ((size_t)(m_base + 16 * (i + ii)) * p.ldc + n0) * 2u;
-          if (full) {
+          if (FULL) {
             rin[ii][0] = *reinterpret_cast<const u4*>(sb + voff);
             rin[ii][1] = *reinterpret_cast<const u4*>(sb + row8 + voff);
           } else {                               // clamped, never masked: rows / columns outside are not stored
@@ -237,56 +247,47 @@ __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4
       u4 x = rin[i % HB][0], y = rin[i % HB][1];
       to_store_order(x, y);                                      // involution: store order -> (q0, q1) of the own row
       swap_pair(x); swap_pair(y);
-      in[0] = __builtin_bit_cast(h4, u2{x[0], x[1]}); in[1] = __builtin_bit_cast(h4, u2{x[2], x[3]});
-      in[2] = __builtin_bit_cast(h4, u2{y[0], y[1]}); in[3] = __builtin_bit_cast(h4, u2{y[2], y[3]});
+      in[0] = unpack2(x[0], x[1]); in[1] = unpack2(x[2], x[3]);
+      in[2] = unpack2(y[0], y[1]); in[3] = unpack2(y[2], y[3]);
     }
-    h4 out[4], pre[4];
+    // out / pre hold the fp32 values whose rounding to fp16 is the result (the pack below rounds exactly once)
+    f4 out[4], pre[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f4 v = acc[i][j];
-      if (flags & EPI_BIAS) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)bias[j][r];
-      }
+      if (flags & EPI_BIAS) v += bias[j];
       if (flags & EPI_QGELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pre[j][r] = (half_t)v[r]; out[j][r] = (half_t)qgelu_f16((float)pre[j][r]); }
+        for (int r = 0; r < 4; ++r) {
+          pre[j][r] = r16(v[r]);
+          float t = r16(1.702f * pre[j][r]);
+          float sg = r16(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)));
+          out[j][r] = pre[j][r] * sg;             // product of two fp16 values: exact in fp32
+        }
       } else if (flags & EPI_DGELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[j][r] = (half_t)(v[r] * qgelu_grad((float)in[j][r]));
+        for (int r = 0; r < 4; ++r) out[j][r] = v[r] * qgelu_grad(in[j][r]);
       } else if (flags & EPI_RESID) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[j][r] = (half_t)((float)in[j][r] + r16(v[r]));
+        for (int r = 0; r < 4; ++r) out[j][r] = in[j][r] + r16(v[r]);
       } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[j][r] = (half_t)v[r];
+        out[j] = v;
       }
     }
-    if (want_csum) {
-      if (full) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) csum[j][r] += (float)out[j][r];
-      } else {
-        const bool row_ok = m_base + 16 * i + c < p.M;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) csum[j][r] += row_ok ? (float)out[j][r] : 0.f;
-      }
+    u4 o0 = pack_pair(out[0], out[1]), o1 = pack_pair(out[2], out[3]);
+    if (want_csum) {                               // sums of the ROUNDED values, as a pass over the stored tensor would see
+      const bool row_ok = FULL || m_base + 16 * i + c < p.M;
+      const f4 w0 = unpack2(o0[0], o0[1]), w1 = unpack2(o0[2], o0[3]), w2 = unpack2(o1[0], o1[1]), w3 = unpack2(o1[2], o1[3]);
+      if (row_ok) { csum[0] += w0; csum[1] += w1; csum[2] += w2; csum[3] += w3; }
     }
-    {
-      u4 o0 = join(out[0], out[1]), o1 = join(out[2], out[3]);
-      swap_pair(o0); swap_pair(o1);
-      to_store_order(o0, o1);
-      store2(p.C, i, o0, o1);
-    }
+    swap_pair(o0); swap_pair(o1);
+    to_store_order(o0, o1);
+    store2(p.C, i, o0, o1);
     if (two) {                                   // the pre-activation, for the backward pass
-      u4 o0 = join(pre[0], pre[1]), o1 = join(pre[2], pre[3]);
-      swap_pair(o0); swap_pair(o1);
-      to_store_order(o0, o1);
-      store2(p.aux_out, i, o0, o1);
+      u4 q0 = pack_pair(pre[0], pre[1]), q1 = pack_pair(pre[2], pre[3]);
+      swap_pair(q0); swap_pair(q1);
+      to_store_order(q0, q1);
+      store2(p.aux_out, i, q0, q1);
     }
   }
   if (want_csum) {                               // 16 lanes c -> one partial row per wave: row block (m_base / (16 MT))
@@ -304,9 +305,15 @@ __device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4
         t[r] = v;
       }
       const int n = n0 + 16 * j + 4 * g;
-      if (c == 0 && n < p.N) *reinterpret_cast<f4*>(dst + 16 * j + 4 * g) = t;
+      if (c == 0 && (FULL || n < p.N)) *reinterpret_cast<f4*>(dst + 16 * j + 4 * g) = t;
     }
   }
+}
+
+template <int MT, int F>
+__device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
+  if (m_base + 16 * MT <= p.M && n0 + 64 <= p.N) epilogue_run<MT, F, true>(p, acc, m_base, n0, lane);    // wave-uniform
+  else epilogue_run<MT, F, false>(p, acc, m_base, n0, lane);
 }
 
 // EPI >= 0: the kernel was instantiated for exactly these flags (straight-line epilogue, its own register budget);
