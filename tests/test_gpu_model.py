@@ -321,3 +321,36 @@ def test_uint8_frames_equal_normalised_fp32_frames():
         out.append((float(loss), model.visual_encoder.visual.conv1.weight.grad.clone()))
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1])
+
+
+def test_step_is_deterministic_across_runs_and_stream_modes():
+    """Two fresh models, same weights and batch: loss and every gradient bit-identical from run to run, and identical with
+    the multi-stream overlap (text tower beside the frame tower, weight gradients on their own stream) switched off.  A
+    missing event between the streams would show up here as a run-to-run difference."""
+    from hmmc_amd.modeling import BirdModel
+    import hmmc_amd.modeling as M
+    import hmmc_amd.functional as Fn2
+    dims = synth.TINY
+    sd = synth.finetune_state(dims)
+    batch = [t.to(DEV) for t in synth.finetune_batch(16, 6, 32, tag="det")]
+
+    def run():
+        model = BirdModel.from_pretrained("cross-base", state_dict=sd, task_config=task_config(max_frames=6)).to(DEV).train()
+        loss = model(*batch, 1)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    saved = (M._OVERLAP_TOWERS, Fn2._WGRAD_STREAM)
+    try:
+        M._OVERLAP_TOWERS, Fn2._WGRAD_STREAM = True, True
+        l1, g1 = run()
+        l2, g2 = run()
+        M._OVERLAP_TOWERS, Fn2._WGRAD_STREAM = False, False
+        l3, g3 = run()
+    finally:
+        M._OVERLAP_TOWERS, Fn2._WGRAD_STREAM = saved
+    assert l1 == l2 == l3, (l1, l2, l3)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), f"run-to-run difference in {n}"
+        assert torch.equal(g1[n], g3[n]), f"overlap on/off difference in {n}"
