@@ -424,12 +424,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
     //     1     A0 (8) + B0 (4)      (a0, b0)          B1 of K-tile t+1
     //     2     B1 (4)               (a0, b1)          A1 of K-tile t+1
     //     3     A1 (8)               (a1, b1)          A0 of K-tile t+2
-    //     4     - (B0 kept)          (a1, b0)          B0 of K-tile t+2, then s_waitcnt vmcnt(4)
+    //     4     - (B0 kept)          (a1, b0)          B0 of K-tile t+2
+    // every load segment ends with s_waitcnt vmcnt(8): all but the four most recently staged halves have landed
     // WAR: a half image is restaged two phases or more after the phase that last read it, so with the groups one
     // barrier apart every read has retired (lgkmcnt before that phase's MFMAs) before the DMA is even issued.
-    // RAW: the vmcnt(4) of phase 4 (everything but A0/B0 of t+2 has landed) precedes the barrier both groups
-    // pass before any wave reads K-tile t+1.  Past the last K-tile the DMA is still issued, out of range
-    // (reads as zero into a dead image), so the count of 4 stays exact.
+    // RAW: a half is read four phases after it was staged.  The vmcnt(8) that closes the load segment of phase q leaves
+    // only the four youngest halves (8 loads per thread) in flight, so the half read in phase q + 1 - staged four
+    // phases before that - has landed, and the wait precedes the barriers both groups pass before that read.  One
+    // counted wait per phase instead of a vmcnt(4) once per K-tile gives every half four phases to arrive instead of
+    // two: operands that stream from HBM (weight gradients) no longer stall the K-tile on their way in.  Past the
+    // last K-tile the DMA is still issued, out of range (reads as zero into a dead image), so the count stays exact;
+    // epilogue stores only make the wait stricter.
     constexpr int HALF = 128 * BKT * 2;
     const unsigned vA = half_vbase<AK, true>(tid, p.lda), vB = half_vbase<BK, false>(tid, p.ldb);
     int s_item = item, s_tm = tm, s_tn = tn, s_kt = kt, s_end = kt_end, s_buf = 0;
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
     stage_a(0); stage_b(0); stage_b(1); stage_a(1);
     s_advance();
     stage_a(0); stage_b(0);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     HMMC_BAR();
     if (wm == 1) HMMC_BAR();
     const int arow = wm * 64, brow = wn * 32;
@@ -484,6 +489,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<AK, 128>(base, arow + i * 16, ks, lane);
       stage_b(1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       HMMC_BAR();
       HMMC_MM(0, 0, b0f);
       HMMC_BAR();
@@ -494,6 +500,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
         for (int j = 0; j < 2; ++j) b1f[ks][j] = read_frag<BK, 128>(base + 3 * HALF, brow + j * 16, ks, lane);
       stage_a(1);
       s_advance();
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       HMMC_BAR();
       HMMC_MM(0, 2, b1f);
       HMMC_BAR();
@@ -503,12 +510,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<AK, 128>(base + HALF, arow + i * 16, ks, lane);
       stage_a(0);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       HMMC_BAR();
       HMMC_MM(4, 2, b1f);
       HMMC_BAR();
       // phase 4
       stage_b(0);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       HMMC_BAR();
       HMMC_MM(4, 0, b0f);
       HMMC_BAR();
