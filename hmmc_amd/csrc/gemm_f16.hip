@@ -228,23 +228,27 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
   for (int i = 0; i < MT; ++i) {
     f4 in[4];
     if (has_src) {
-      if (i % HB == 0) {
+      auto load_strip = [&](int slot, int strip) {
+        const char* sb = src + ((size_t)(m_base + 16 * strip) * p.ldc + n0) * 2u;
+        if (FULL) {
+          rin[slot][0] = *reinterpret_cast<const u4*>(sb + voff);
+          rin[slot][1] = *reinterpret_cast<const u4*>(sb + row8 + voff);
+        } else {                                 // clamped, never masked: rows / columns outside are not stored
 #pragma unroll
-        for (int ii = 0; ii < HB; ++ii) {
-          const char* sb = src + ((size_t)(m_base + 16 * (i + ii)) * p.ldc + n0) * 2u;
-          if (FULL) {
-            rin[ii][0] = *reinterpret_cast<const u4*>(sb + voff);
-            rin[ii][1] = *reinterpret_cast<const u4*>(sb + row8 + voff);
-          } else {                               // clamped, never masked: rows / columns outside are not stored
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const int m = min(m_base + 16 * (i + ii) + 8 * t + r_l, p.M - 1);
-              rin[ii][t] = *reinterpret_cast<const u4*>(src + ((size_t)m * p.ldc + (n_ok ? n0 + n_l : 0)) * 2u);
-            }
+          for (int t = 0; t < 2; ++t) {
+            const int m = min(m_base + 16 * strip + 8 * t + r_l, p.M - 1);
+            rin[slot][t] = *reinterpret_cast<const u4*>(src + ((size_t)m * p.ldc + (n_ok ? n0 + n_l : 0)) * 2u);
           }
         }
+      };
+      if (i == 0) {
+#pragma unroll
+        for (int ii = 0; ii < HB; ++ii) load_strip(ii, ii);
       }
       u4 x = rin[i % HB][0], y = rin[i % HB][1];
+      // the slot is free again: request strip i + HB now, ahead of this strip's arithmetic and stores, so the second
+      // half of the operand arrives while the first half is being processed
+      if (i + HB < MT) load_strip(i % HB, i + HB);
       to_store_order(x, y);                                      // involution: store order -> (q0, q1) of the own row
       swap_pair(x); swap_pair(y);
       in[0] = unpack2(x[0], x[1]); in[1] = unpack2(x[2], x[3]);
