@@ -12,6 +12,8 @@ Stage -> reference lines:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -103,7 +105,7 @@ def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep):
     return y, (acts if keep else None)
 
 
-_WGRAD_STREAM = __import__("os").environ.get("HMMC_WGRAD_STREAM", "1") != "0"
+_WGRAD_STREAM = os.environ.get("HMMC_WGRAD_STREAM", "1") != "0"
 
 
 def _tower_backward(dy, x0, params, acts, nseq, L, heads, causal, fp32):
