@@ -43,12 +43,17 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // round-trip through fp16 (the reference rounds at every fp16 tensor op)
 __device__ __forceinline__ float r16(float x) { return (float)(half_t)x; }
+// the same with the fp32 value pinned first: torch computes `half_tensor * python_float` as an fp32 product that is THEN
+// rounded to fp16 (two roundings); left alone, hipcc fuses product and conversion into v_fma_mixlo_f16 (one rounding),
+// which differs on fp32 ties (0.02 % of QuickGELU inputs)
+__device__ __forceinline__ float opq(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ float r16s(float x) { return (float)(half_t)opq(x); }
 
 // QuickGELU evaluated with the reference's fp16 rounding points
 // (modules/module_clip.py:226-228: x * sigmoid(1.702 * x) on an fp16 tensor).  exp(-t) = exp2(-log2(e) t): one
 // multiply + v_exp_f32; v_rcp_f32 is 1 ulp, far inside the fp16 rounding that follows.
 __device__ __forceinline__ float qgelu_f16(float h) {
-  float t = r16(1.702f * h);
+  float t = r16s(1.702f * h);
   float s = r16(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)));
   return r16(h * s);
 }

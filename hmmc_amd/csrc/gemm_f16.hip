@@ -29,7 +29,7 @@ namespace {
 
 constexpr int BKT = 64;
 
-enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32 };
+enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32, EPI_SAVE_DGELU = 64, EPI_MULAUX = 128 };
 
 struct GemmArgs {
   const half_t* A; const half_t* B; half_t* C;
@@ -205,8 +205,8 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
       bias[j] = f4{(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
     }
   }
-  const bool has_src = flags & (EPI_DGELU | EPI_RESID);
-  const char* src = reinterpret_cast<const char*>((flags & EPI_DGELU) ? p.aux_in : p.resid);
+  const bool has_src = flags & (EPI_DGELU | EPI_MULAUX | EPI_RESID);
+  const char* src = reinterpret_cast<const char*>((flags & (EPI_DGELU | EPI_MULAUX)) ? p.aux_in : p.resid);
   constexpr int HB = MT > 4 ? 4 : MT;            // strips whose operand loads are in flight together (32 VGPRs)
   u4 rin[HB][2];
   const bool two = (flags & EPI_QGELU) && p.aux_out;
@@ -263,14 +263,19 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
       if (flags & EPI_QGELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pre[j][r] = r16(v[r]);
-          float t = r16(1.702f * pre[j][r]);
-          float sg = r16(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f)));
-          out[j][r] = pre[j][r] * sg;             // product of two fp16 values: exact in fp32
+          const float h = r16(v[r]);
+          const float t = r16s(1.702f * h);        // fp32 product, then fp16: torch's two roundings (see r16s)
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
+          out[j][r] = h * r16(sg);                // product of two fp16 values: exact in fp32
+          // aux: the pre-activation h, or (EPI_SAVE_DGELU) QuickGELU'(h) = s + 1.702 h s (1 - s) so that the backward
+          // GEMM multiplies by it (EPI_MULAUX) instead of evaluating exp and rcp again
+          pre[j][r] = (flags & EPI_SAVE_DGELU) ? __builtin_fmaf(1.702f * h * (1.0f - sg), sg, sg) : h;
         }
       } else if (flags & EPI_DGELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[j][r] = v[r] * qgelu_grad(in[j][r]);
+      } else if (flags & EPI_MULAUX) {
+        out[j] = v * in[j];
       } else if (flags & EPI_RESID) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[j][r] = in[j][r] + r16(v[r]);
@@ -657,11 +662,13 @@ void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stre
       case EPI_BIAS: return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS>(p, grid, stream);
       case EPI_BIAS | EPI_RESID: return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS | EPI_RESID>(p, grid, stream);
       case EPI_BIAS | EPI_QGELU: return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS | EPI_QGELU>(p, grid, stream);
+      case EPI_BIAS | EPI_QGELU | EPI_SAVE_DGELU:
+        return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS | EPI_QGELU | EPI_SAVE_DGELU>(p, grid, stream);
       default: return launch_one<true, true, BM, BN, WM, WN, -1>(p, grid, stream);
     }
   } else if (ak && !bk) {         // dgrad: dx = dy W
     if (f == 0) return launch_one<true, false, BM, BN, WM, WN, 0>(p, grid, stream);
-    if (p.csum && (p.flags & ~EPI_COLSUM) == EPI_DGELU) return launch_one<true, false, BM, BN, WM, WN, EPI_DGELU | EPI_COLSUM>(p, grid, stream);
+    if (p.csum && (p.flags & ~EPI_COLSUM) == EPI_MULAUX) return launch_one<true, false, BM, BN, WM, WN, EPI_MULAUX | EPI_COLSUM>(p, grid, stream);
     if (f == EPI_DGELU) return launch_one<true, false, BM, BN, WM, WN, EPI_DGELU>(p, grid, stream);
     return launch_one<true, false, BM, BN, WM, WN, -1>(p, grid, stream);
   } else if (!ak && !bk) {        // wgrad: dW = dy^T x
@@ -728,7 +735,7 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
   if (!a_kmajor && (M & 7)) return HMMC_ERR_UNSUPPORTED;
   if ((epilogue & EPI_BIAS) && !bias) return HMMC_ERR_ARG;
   if ((epilogue & EPI_RESID) && !resid) return HMMC_ERR_ARG;
-  if ((epilogue & EPI_DGELU) && !aux_in) return HMMC_ERR_ARG;
+  if ((epilogue & (EPI_DGELU | EPI_MULAUX)) && !aux_in) return HMMC_ERR_ARG;
   // extents of the operand buffers (bytes); 32-bit buffer offsets
   uint64_t a_bytes = a_kmajor ? ((uint64_t)(M - 1) * lda + K) * 2 : ((uint64_t)(K - 1) * lda + M) * 2;
   uint64_t b_bytes = b_kmajor ? ((uint64_t)(N - 1) * ldb + K) * 2 : ((uint64_t)(K - 1) * ldb + N) * 2;
@@ -771,7 +778,7 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
     rec.flops = 2.0 * M * N * K;
     double mn = (double)M * N;
     rec.bytes = 2.0 * ((double)M * K + (double)N * K + mn) + ((epilogue & EPI_BIAS) ? 2.0 * N : 0.0) +
-                2.0 * mn * (((epilogue & EPI_RESID) ? 1 : 0) + ((epilogue & EPI_DGELU) ? 1 : 0) + (aux_out ? 1 : 0));
+                2.0 * mn * (((epilogue & EPI_RESID) ? 1 : 0) + ((epilogue & (EPI_DGELU | EPI_MULAUX)) ? 1 : 0) + (aux_out ? 1 : 0));
     rec.layout = a_kmajor ? (b_kmajor ? 0 : 1) : 2;
     (void)hipEventRecord(rec.e0, stream);
   }

@@ -21,9 +21,7 @@ constexpr int CHUNK = 32768;
 // The reference evaluates every fp16 tensor op as: fp32 arithmetic, round to fp32, then round to fp16.
 // hipcc would fuse "multiply, convert" into v_fma_mixlo_f16 (ONE rounding from the exact product) and
 // contract separate mul/add into fma; both differ from the reference in the last fp16 bit on ties.
-// opq() makes a value opaque to the optimizer, pinning an fp32 rounding point.
-__device__ __forceinline__ float opq(float x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ float r16s(float x) { return (float)(half_t)opq(x); }
+// opq() / r16s() (common.h) make a value opaque to the optimizer, pinning an fp32 rounding point.
 
 __device__ __forceinline__ float block_sum(float v) {
   __shared__ float red[4];

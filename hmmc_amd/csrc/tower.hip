@@ -32,7 +32,7 @@ int hmmc_temporal_attention_bwd(const float*, const float*, const float*, float*
 
 namespace {
 
-enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32 };
+enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32, EPI_SAVE_DGELU = 64, EPI_MULAUX = 128 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -169,7 +169,9 @@ extern "C" int hmmc_tower_fwd(const void* x, void* y, const void* const* params,
     else CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
     CK(linear(f32, a.att, P[4], a.x1, (int)T, D, D, P[5], xin, nullptr, 0, workspace, ws_bytes, s));
     CK(hmmc_layernorm_fwd(a.x1, (const float*)P[6], (const float*)P[7], a.ln2, a.m2, a.r2, nullptr, (int)T, D, D, eps, dt, s));
-    CK(linear(f32, a.ln2, P[8], a.g, (int)T, 4 * D, D, P[9], nullptr, keep_acts ? a.h : nullptr, EPI_QGELU, workspace, ws_bytes, s));
+    // fp16 tower: the `h` slot receives QuickGELU'(pre-activation), which is all the backward needs of it
+    CK(linear(f32, a.ln2, P[8], a.g, (int)T, 4 * D, D, P[9], nullptr, keep_acts ? a.h : nullptr,
+              EPI_QGELU | ((!f32 && keep_acts) ? EPI_SAVE_DGELU : 0), workspace, ws_bytes, s));
     // output of this layer: next layer's saved input slot, or y for the last layer.  Without saved activations one
     // slab is reused: the output alternates between the x and h slots (h is dead once c_proj has read g, and the
     // next layer's input is dead before its own c_fc rewrites h).
@@ -268,7 +270,7 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
       CK(hmmc_colsum(dh, G[9], (int)T, 4 * D, 4 * D, dt, dt, 0, workspace, gen, s));
     } else {
       const int rows = (int)hmmc_gemm_f16_colsum_rows((int)T, 4 * D, D);
-      CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_DGELU, s, part, part_bytes));
+      CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_MULAUX, s, part, part_bytes));
       CK(hmmc_colsum(part, G[9], rows, 4 * D, 4 * D, 1, dt, 0, workspace, gen, s));
     }
     CK(side_wgrad(1, dh, a.ln2, G[8], 4 * D, D));

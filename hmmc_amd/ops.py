@@ -13,6 +13,7 @@ from ._lib import call, ptr, query
 
 EPI_BIAS, EPI_RESID, EPI_QGELU, EPI_DGELU = 1, 2, 4, 8
 EPI_COLSUM = 32
+EPI_SAVE_DGELU, EPI_MULAUX = 64, 128
 
 _ws_cache = {}
 
@@ -85,7 +86,7 @@ def gemm_f16(a, b, M, N, K, a_kmajor=True, b_kmajor=True, bias=None, resid=None,
         assert tuple(resid.shape) == (M, N)
         epilogue |= EPI_RESID
     if aux_in is not None:
-        assert tuple(aux_in.shape) == (M, N)
+        assert tuple(aux_in.shape) == (M, N) and epilogue & (EPI_DGELU | EPI_MULAUX)
     if want_colsum:                               # fp32 partial column sums of C, one row per 128 / 64 output rows
         rows = query("hmmc_gemm_f16_colsum_rows", M, N, K)
         part = torch.empty((rows, N), dtype=torch.float32, device=a.device)

@@ -35,6 +35,8 @@ typedef void* hmmc_stream_t; /* hipStream_t */
 #define HMMC_EPI_RESID 2 /* out = fp16(resid + fp16(acc + bias))        */
 #define HMMC_EPI_QGELU 4 /* out = QuickGELU(h), aux_out = h = fp16(acc + bias) */
 #define HMMC_EPI_DGELU 8 /* out = acc * QuickGELU'(aux_in)              */
+#define HMMC_EPI_SAVE_DGELU 64 /* with QGELU: aux_out = QuickGELU'(h) instead of h (what the backward multiplies by) */
+#define HMMC_EPI_MULAUX 128 /* out = acc * aux_in (backward of QuickGELU with the saved derivative)        */
 #define HMMC_EPI_COLSUM 32 /* + fp32 partial column sums of C into `workspace` (see hmmc_gemm_f16_colsum_rows) */
 
 /* fp16 MFMA GEMM, fp32 accumulate: C[M,N] = epilogue(sum_k Aop[m][k] * Bop[n][k]).

@@ -17,8 +17,9 @@ for name, lay, M, N, K, epi in shapes:
     kw = {}
     if "b" in epi: kw["bias"] = torch.randn(N, device="cuda", generator=g).half()
     if "r" in epi: kw["resid"] = torch.randn(M, N, device="cuda", generator=g).half()
-    if "g" in epi: kw.update(epilogue=ops.EPI_QGELU, want_aux=True)
-    if "d" in epi: kw.update(epilogue=ops.EPI_DGELU, aux_in=torch.randn(M, N, device="cuda", generator=g).half(), want_colsum=True)
+    new = hasattr(ops, "EPI_MULAUX") and not os.environ.get("HMMC_LIB")
+    if "g" in epi: kw.update(epilogue=ops.EPI_QGELU | (ops.EPI_SAVE_DGELU if new else 0), want_aux=True)
+    if "d" in epi: kw.update(epilogue=ops.EPI_MULAUX if new else ops.EPI_DGELU, aux_in=torch.randn(M, N, device="cuda", generator=g).half(), want_colsum=True)
     if lay == "kk":
         a = torch.randn(M, K, device="cuda", generator=g).half(); b = (torch.randn(N, K, device="cuda", generator=g) * 0.05).half()
         f = lambda: ops.gemm_f16(a, b, M, N, K, **kw)

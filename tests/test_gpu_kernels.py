@@ -98,6 +98,12 @@ def test_gemm_random_and_epilogues():
     s = torch.sigmoid(1.702 * h.float())
     dref = acc * (s * (1 + 1.702 * h.float() * (1 - s)))
     assert relerr(dh, dref) < 2e-3
+    # the towers' pairing: the forward saves QuickGELU'(h), the backward multiplies by it
+    g2, gf = ops.gemm_f16(a, w, M, N, K, bias=bias, epilogue=ops.EPI_QGELU | ops.EPI_SAVE_DGELU, want_aux=True)
+    assert torch.equal(g2, g)
+    assert relerr(gf, s * (1 + 1.702 * h.float() * (1 - s))) < 1e-3
+    dh2 = ops.gemm_f16(a, w, M, N, K, aux_in=gf, epilogue=ops.EPI_MULAUX)
+    assert relerr(dh2, dref) < 2e-3
 
 
 @pytest.mark.parametrize("b_kmajor", [True, False])
