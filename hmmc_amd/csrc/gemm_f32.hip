@@ -98,6 +98,86 @@ __device__ __forceinline__ void store_op(float* S, f4 v, bool kcontig, int tid) 
   }
 }
 
+// epilogue of one 16x16 MFMA tile: this lane's 4 consecutive outputs C[m][n .. n+3]
+__device__ __forceinline__ void store_tile16(const G32& p, f4 v, int m, int n) {
+  if (m >= p.M || n >= p.N) return;
+  long off = (long)m * p.ldc + n;
+  bool full = p.cvec && n + 3 < p.N;
+  float o[4], hsave[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float t = v[r] * p.alpha;
+    if ((p.flags & EPI_BIAS) && n + r < p.N) t += p.bias[n + r];
+    hsave[r] = t;
+    if (p.flags & EPI_QGELU) t = qgelu32(t);
+    else if (p.flags & EPI_RELU) t = fmaxf(t, 0.f);
+    else if ((p.flags & EPI_DGELU) && n + r < p.N) t *= qgelu_grad(p.aux_in[off + r]);
+    if ((p.flags & EPI_RESID) && n + r < p.N) t += p.resid[off + r];
+    o[r] = t;
+  }
+  if (full) {
+    *reinterpret_cast<f4*>(p.C + off) = f4{o[0], o[1], o[2], o[3]};
+    if (p.aux_out) *reinterpret_cast<f4*>(p.aux_out + off) = f4{hsave[0], hsave[1], hsave[2], hsave[3]};
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < p.N) { p.C[off + r] = o[r]; if (p.aux_out) p.aux_out[off + r] = hsave[r]; }
+  }
+}
+
+// ---- small problems: one wave per workgroup, 16 x 32 outputs, operands straight from global memory into the MFMA --------
+// A problem with fewer 64x64 tiles than CUs (the temporal transformer at a few hundred tokens, the similarity heads) is
+// latency-bound in the kernel below: each of its few workgroups walks K in 16-deep steps of 16 MFMAs behind an LDS round trip
+// and a barrier.  Here a wave owns a 16 x 32 tile (8 MFMAs per step, 8x as many workgroups), and because the k index an MFMA
+// lane group consumes is free to choose, lane (r = lane & 15, kg = lane >> 4) simply takes k = k0 + 4 kg + s in sub-step s:
+// for a k-contiguous operand that is one 16-byte load of its own row, for a row-contiguous one four coalesced 4-byte loads.
+// No LDS, no barrier; the loads of the next two steps are in flight while a step computes.
+__device__ __forceinline__ f4 small_frag(const float* P, long sr, long sk, int R, int K, int row, int k, bool vec) {
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  const float* p = P + (long)row * sr + (long)k * sk;           // row already clamped into [0, R)
+  if (sk == 1 && vec && k + 3 < K) return *reinterpret_cast<const f4*>(p);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) if (k + s < K) v[s] = p[(long)s * sk];
+  return v;
+}
+
+__global__ __launch_bounds__(64) void gemm_f32_small_kernel(G32 p) {
+  const int lane = threadIdx.x;
+  const int ntn = (p.N + 31) / 32;
+  const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+  const int m0 = tm * 16, n0 = tn * 32;
+  const int r = lane & 15, kg = lane >> 4;
+  const int ma = min(m0 + r, p.M - 1), nb0 = min(n0 + r, p.N - 1), nb1 = min(n0 + 16 + r, p.N - 1);
+  f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+  constexpr int PD = 3;
+  const int nkt = (p.K + 15) / 16;
+  f4 fa[PD], fb0[PD], fb1[PD];
+  auto fetch = [&](int kt, f4& a, f4& b0, f4& b1) {
+    const int k = kt * 16 + 4 * kg;
+    a = small_frag(p.A, p.sam, p.sak, p.M, p.K, ma, k, p.avec);
+    b0 = small_frag(p.B, p.sbn, p.sbk, p.N, p.K, nb0, k, p.bvec);
+    b1 = small_frag(p.B, p.sbn, p.sbk, p.N, p.K, nb1, k, p.bvec);
+  };
+#pragma unroll
+  for (int s = 0; s < PD; ++s) fetch(s, fa[s], fb0[s], fb1[s]);      // past K: zeros
+  auto step = [&](int kt, f4& a, f4& b0, f4& b1) {
+    const f4 ca = a, cb0 = b0, cb1 = b1;
+    fetch(kt + PD, a, b0, b1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb0[s], ca[s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb1[s], ca[s], acc[1], 0, 0, 0);
+    }
+  };
+  for (int kt = 0; kt < nkt; kt += PD) {
+    step(kt, fa[0], fb0[0], fb1[0]);
+    if (kt + 1 < nkt) step(kt + 1, fa[1], fb0[1], fb1[1]);
+    if (kt + 2 < nkt) step(kt + 2, fa[2], fb0[2], fb1[2]);
+  }
+  store_tile16(p, acc[0], m0 + r, n0 + 4 * kg);
+  store_tile16(p, acc[1], m0 + r, n0 + 16 + 4 * kg);
+}
+
 __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
   __shared__ __attribute__((aligned(16))) float sA[2][TK * LDS_LD];
   __shared__ __attribute__((aligned(16))) float sB[2][TK * LDS_LD];
@@ -165,38 +245,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
   }
   // lane owns C[m = .. + (lane & 15)][n = .. + 4*(lane >> 4) + r]
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int m = m0 + wm * 32 + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int n = n0 + wn * 32 + j * 16 + 4 * (lane >> 4);
-      if (n >= p.N) continue;
-      f4 v = acc[i][j];
-      long off = (long)m * p.ldc + n;
-      bool full = p.cvec && n + 3 < p.N;
-      float o[4], hsave[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = v[r] * p.alpha;
-        if ((p.flags & EPI_BIAS) && n + r < p.N) t += p.bias[n + r];
-        hsave[r] = t;
-        if (p.flags & EPI_QGELU) t = qgelu32(t);
-        else if (p.flags & EPI_RELU) t = fmaxf(t, 0.f);
-        else if ((p.flags & EPI_DGELU) && n + r < p.N) t *= qgelu_grad(p.aux_in[off + r]);
-        if ((p.flags & EPI_RESID) && n + r < p.N) t += p.resid[off + r];
-        o[r] = t;
-      }
-      if (full) {
-        *reinterpret_cast<f4*>(p.C + off) = f4{o[0], o[1], o[2], o[3]};
-        if (p.aux_out) *reinterpret_cast<f4*>(p.aux_out + off) = f4{hsave[0], hsave[1], hsave[2], hsave[3]};
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) { p.C[off + r] = o[r]; if (p.aux_out) p.aux_out[off + r] = hsave[r]; }
-      }
-    }
-  }
+    for (int j = 0; j < 2; ++j)
+      store_tile16(p, acc[i][j], m0 + wm * 32 + i * 16 + (lane & 15), n0 + wn * 32 + j * 16 + 4 * (lane >> 4));
 }
 
 }  // namespace
@@ -220,6 +272,18 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
   p.bvec = !(b_ld & 3) && !((uintptr_t)B & 15);
   p.cvec = !(ldc & 3) && !((uintptr_t)C & 15) && (!aux_out || !((uintptr_t)aux_out & 15));
   long blocks = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  static const int num_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  // fewer 64x64 tiles than CUs: latency-bound, take the one-wave 16x32 kernel - unless both operands are row-contiguous
+  // (weight gradients): their fragments cost four 4-byte loads each there, and the LDS kernel is faster (measured)
+  if (blocks < num_cu && (sak == 1 || sbk == 1)) {
+    long small = (long)((M + 15) / 16) * ((N + 31) / 32);
+    hipLaunchKernelGGL(gemm_f32_small_kernel, dim3((unsigned)small), dim3(64), 0, stream, p);
+    return hmmc_launch_status();
+  }
   hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
   return hmmc_launch_status();
 }
