@@ -422,10 +422,16 @@ extern "C" int hmmc_layernorm_fwd(const void* x, const float* gamma, const float
   return hmmc_launch_status();
 }
 
-extern "C" size_t hmmc_layernorm_bwd_workspace(int rows, int D) {
-  int nb = (rows + 3) / 4;
+// blocks of the LayerNorm backward = rows of its partial matrix: 8 rows per wave at least (the second-stage reduce reads
+// nb x 3D floats, which at a few thousand rows would otherwise cost as much as the backward itself), 1024 blocks at most
+static inline int ln_bwd_blocks(int rows) {
+  int nb = (rows + 31) / 32;
   if (nb > 1024) nb = 1024;
-  return (size_t)nb * 3 * D * sizeof(float);
+  return nb < 1 ? 1 : nb;
+}
+
+extern "C" size_t hmmc_layernorm_bwd_workspace(int rows, int D) {
+  return (size_t)ln_bwd_blocks(rows) * 3 * D * sizeof(float);
 }
 
 // dx rows are written at the same (row_index, in_stride) positions the forward read x from.
@@ -438,8 +444,7 @@ extern "C" int hmmc_layernorm_bwd(const void* dy, const void* x, const float* ga
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0) return HMMC_ERR_ARG;
   int vn = dtype == 0 ? 8 : 4;
   if (D % vn || D > LN_MAXD || in_stride % vn) return HMMC_ERR_UNSUPPORTED;
-  int nb = (rows + 3) / 4;
-  if (nb > 1024) nb = 1024;
+  const int nb = ln_bwd_blocks(rows);
   const int np = dx_colsum ? 3 : 2;
   if (!workspace || ws_bytes < (size_t)nb * np * D * sizeof(float)) return HMMC_ERR_WORKSPACE;
   float* partial = (float*)workspace;
