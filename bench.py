@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--length", type=int, default=32)
     ap.add_argument("--clip", default="ViT-B/32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="run everything on one stream (no tower / weight-gradient overlap): the mode whose rocprofv3 "
+                         "per-kernel averages are comparable with roofline.avg_launch_us")
     ap.add_argument("--roofline-steps", type=int, default=3,
                     help="extra single-stream steps after the timed region over which the GEMM launches are timed with HIP events")
     args = ap.parse_args()
@@ -141,6 +144,10 @@ def main():
     from hmmc_amd.modeling import BirdModel
     from hmmc_amd.optimization import clip_grad_norm_
 
+    if args.single_stream:
+        import hmmc_amd.functional as _fn0
+        import hmmc_amd.modeling as _md0
+        _md0._OVERLAP_TOWERS, _fn0._WGRAD_STREAM = False, False
     assert args.batch % world == 0
     b = args.batch // world
     cfg = task_config(local_rank=local_rank, rank=rank, max_frames=args.frames, pretrained_clip_name=args.clip)
@@ -234,7 +241,7 @@ def main():
                "config": {"workload": f"{args.clip} english MSR-VTT fine-tune step, global B={args.batch} F={args.frames} "
                                       f"L_text={args.length}, 224x224, fwd+bwd+clip+BertAdam, random-init weights",
                           "global_batch": args.batch, "per_gpu_batch": b, "frames": args.frames,
-                          "parallelism": f"dp{world}"},
+                          "parallelism": f"dp{world}", "streams": "single" if args.single_stream else "overlapped"},
                "step_tflops": round(value * FLOP_PER_PAIR_TRAIN / 1e12, 1) if args.clip == "ViT-B/32" and args.frames == 12 else None,
                "mfma_frac_whole_step": round(value * FLOP_PER_PAIR_TRAIN / 1e12 / (world * MFMA_PEAK_TFLOPS), 4)
                if args.clip == "ViT-B/32" and args.frames == 12 else None,
