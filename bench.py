@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--single-stream", action="store_true",
                     help="run everything on one stream (no tower / weight-gradient overlap): the mode whose rocprofv3 "
                          "per-kernel averages are comparable with roofline.avg_launch_us")
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="compute units kept out of the GEMM grids for RCCL (default: 16 when --gpus > 1, else 0); "
+                         "giving it with --gpus 1 measures what the reservation costs")
     ap.add_argument("--roofline-steps", type=int, default=3,
                     help="extra single-stream steps after the timed region over which the GEMM launches are timed with HIP events")
     args = ap.parse_args()
@@ -144,6 +147,9 @@ def main():
     from hmmc_amd.modeling import BirdModel
     from hmmc_amd.optimization import clip_grad_norm_
 
+    if args.reserve_cus is not None:
+        os.environ["HMMC_RCCL_CUS"] = str(args.reserve_cus)
+    reserved = ops.reserve_cus_for_collectives() if (world > 1 or args.reserve_cus is not None) else 0
     if args.single_stream:
         import hmmc_amd.functional as _fn0
         import hmmc_amd.modeling as _md0
@@ -241,7 +247,8 @@ def main():
                "config": {"workload": f"{args.clip} english MSR-VTT fine-tune step, global B={args.batch} F={args.frames} "
                                       f"L_text={args.length}, 224x224, fwd+bwd+clip+BertAdam, random-init weights",
                           "global_batch": args.batch, "per_gpu_batch": b, "frames": args.frames,
-                          "parallelism": f"dp{world}", "streams": "single" if args.single_stream else "overlapped"},
+                          "parallelism": f"dp{world}", "streams": "single" if args.single_stream else "overlapped",
+                          "gemm_reserved_cus": reserved},
                "step_tflops": round(value * FLOP_PER_PAIR_TRAIN / 1e12, 1) if args.clip == "ViT-B/32" and args.frames == 12 else None,
                "mfma_frac_whole_step": round(value * FLOP_PER_PAIR_TRAIN / 1e12 / (world * MFMA_PEAK_TFLOPS), 4)
                if args.clip == "ViT-B/32" and args.frames == 12 else None,

@@ -613,17 +613,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 struct TileCfg { int bm, bn, splitk; };
 
+int g_reserved_cus = 0;      // hmmc_gemm_reserve_cus
+
+// compute units the persistent grids may occupy
+int gemm_cus() {
+  static const int num_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  return num_cu - g_reserved_cus > 8 ? num_cu - g_reserved_cus : 8;
+}
+
 // Large tower GEMMs take the 256x256 tile; anything that would leave most of a 256-wide tile empty, or
 // that cannot fill the chip with 256x256 tiles even after splitting K, takes 128x128.
 TileCfg pick_cfg(int M, int N, int K, bool allow_split) {
   const int nkt = (K + BKT - 1) / BKT;
   auto tiles_of = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  const int cus = gemm_cus();
   TileCfg c;
   bool big = (M % 256 == 0 || M >= 2048) && (N % 256 == 0 || N >= 2048) && M >= 256 && N >= 256;
   if (big) {
     long t = tiles_of(256, 256);
     long reach = allow_split ? t * (nkt / 8 > 0 ? nkt / 8 : 1) : t;
-    if (reach < 192) big = false;            // cannot occupy most of the 256 CUs
+    if (reach < cus * 3 / 4) big = false;    // cannot occupy most of the CUs
   }
   c.bm = c.bn = big ? 256 : 128;
   c.splitk = 1;
@@ -631,7 +644,7 @@ TileCfg pick_cfg(int M, int N, int K, bool allow_split) {
     // one resident workgroup per CU (two for the small tile): split K just far enough to fill the chip once,
     // so the fp32 slab traffic (splitk * M * N * 8 bytes written + read) stays small
     long t = tiles_of(c.bm, c.bn);
-    long slots = big ? 256 : 512;
+    long slots = big ? cus : 2 * cus;
     if (t * 2 <= slots && nkt >= 8) {
       long s = slots / t;
       if (s > nkt / 4) s = nkt / 4;
@@ -714,6 +727,15 @@ extern "C" int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seco
   return HMMC_OK;
 }
 
+// Compute units the persistent grid leaves free.  The 256x256 kernel holds a CU's whole register file and most of its
+// LDS for the length of a launch, so a collective's workgroups (RCCL under data parallelism) would otherwise only be
+// placed at kernel boundaries, and the next GEMM's workgroups would then queue behind them.
+extern "C" int hmmc_gemm_reserve_cus(int cus) {
+  if (cus < 0 || cus > 128) return HMMC_ERR_ARG;
+  g_reserved_cus = cus;
+  return HMMC_OK;
+}
+
 // rows of the fp32 [rows][N] partial matrix an EPI_COLSUM launch writes into `workspace`
 extern "C" size_t hmmc_gemm_f16_colsum_rows(int M, int N, int K) {
   TileCfg c = pick_cfg(M, N, K, false);
@@ -765,12 +787,8 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
   p.ws = (float*)workspace;
   long tiles = (long)((M + cfg.bm - 1) / cfg.bm) * ((N + cfg.bn - 1) / cfg.bn);
   long items = tiles * splitk;
-  static const int num_cu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
-  long resident = (long)num_cu * (cfg.bm == 256 ? 1 : 2);       // workgroups the LDS budget keeps resident
+  const int cus = gemm_cus();
+  long resident = (long)cus * (cfg.bm == 256 ? 1 : 2);          // workgroups the LDS budget keeps resident
   dim3 grid((unsigned)(items < resident ? items : resident));
   GemmProfRec rec{};
   if (g_prof_on) {

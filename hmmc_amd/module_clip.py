@@ -79,6 +79,8 @@ class Transformer(nn.Module):
         per = self.layers
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             per = max(1, min(self.layers, int(self.ddp_layers_per_node)))
+            from . import ops
+            ops.reserve_cus_for_collectives()
         blocks = list(self.resblocks)
         for i in range(0, self.layers, per):
             params = []

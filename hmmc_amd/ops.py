@@ -17,6 +17,23 @@ EPI_SAVE_DGELU, EPI_MULAUX = 64, 128
 
 _ws_cache = {}
 
+_reserved = None
+
+
+def reserve_cus_for_collectives():
+    """Called by the towers when they run under data parallelism: keep `HMMC_RCCL_CUS` (default 16 of 256) compute units
+    out of the persistent GEMM grids so RCCL's all-reduce workgroups run beside them (include/hmmc_hip.h,
+    hmmc_gemm_reserve_cus).  Idempotent."""
+    global _reserved
+    if _reserved is None:
+        import os
+        _reserved = int(os.environ.get("HMMC_RCCL_CUS", "16"))
+        rc = _lib.load().hmmc_gemm_reserve_cus(_reserved)
+        if rc:
+            raise RuntimeError(f"hmmc_gemm_reserve_cus({_reserved}) failed: {_lib.ERRORS.get(rc, rc)}")
+    return _reserved
+
+
 def gemm_profile_start():
     """bench.py: time every hmmc_gemm_f16 launch (also those issued by the native tower runtime) with HIP events
     recorded on the launch stream."""

@@ -56,6 +56,10 @@ size_t hmmc_gemm_f16_colsum_rows(int M, int N, int K);
  * returns, per operand layout (0 forward, 1 dgrad, 2 wgrad), the summed 2MNK flops, algorithmic operand bytes, seconds and launch counts. */
 int hmmc_gemm_profile_start(void);
 int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seconds, long* launches);
+/* Leave `cus` (0..128, default 0) compute units out of every later hmmc_gemm_f16 grid.  The host sets this once when
+ * gradients are all-reduced while the backward pass runs (DistributedDataParallel at main_task_retrieval.py:207, main_pretrain.py:204), so that
+ * RCCL's workgroups find free CUs instead of waiting for a persistent GEMM grid to drain.  Process-wide. */
+int hmmc_gemm_reserve_cus(int cus);
 int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor,
                   int b_kmajor, const void* bias, const void* resid, void* aux_out, const void* aux_in, int epilogue,
                   void* workspace, size_t ws_bytes, hmmc_stream_t stream);

@@ -79,6 +79,26 @@ def test_gemm_big_tile_exact_integers(layout, M, N, K):
     assert torch.equal(c.float(), ref), f"max diff {(c.float()-ref).abs().max()}"
 
 
+def test_gemm_with_reserved_cus():
+    """hmmc_gemm_reserve_cus only shrinks the persistent grid: results are unchanged, bad counts are refused."""
+    from hmmc_amd import _lib
+    lib = _lib.load()
+    assert lib.hmmc_gemm_reserve_cus(-1) == -1 and lib.hmmc_gemm_reserve_cus(129) == -1
+    M, N, K = 20000, 2304, 768
+    a, b = ints(M, K, lo=-1, hi=2), ints(N, K, lo=-1, hi=2, seed=1)
+    ref = ops.gemm_f16(a, b, M, N, K)
+    try:
+        for cus in (16, 100):
+            assert lib.hmmc_gemm_reserve_cus(cus) == 0
+            assert torch.equal(ops.gemm_f16(a, b, M, N, K), ref)
+            dy, x = ints(12800, 768, lo=-1, hi=2), ints(12800, 384, lo=-1, hi=2, seed=1)
+            c = ops.gemm_f16(dy, x, 768, 384, 12800, a_kmajor=False, b_kmajor=False)
+            assert torch.equal(c.float(), dy.float().t() @ x.float())
+    finally:
+        assert lib.hmmc_gemm_reserve_cus(0) == 0
+    assert torch.equal(ref.float(), a.float() @ b.float().t())
+
+
 def test_gemm_random_and_epilogues():
     M, N, K = 1000, 384, 256
     a, w = rnd(M, K, scale=0.5), rnd(N, K, scale=0.1, seed=1)
