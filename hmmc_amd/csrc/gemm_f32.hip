@@ -125,57 +125,85 @@ __device__ __forceinline__ void store_tile16(const G32& p, f4 v, int m, int n) {
   }
 }
 
-// ---- small problems: one wave per workgroup, 16 x 32 outputs, operands straight from global memory into the MFMA --------
+// ---- small problems: four waves per 16 x 32 output tile, operands straight from global memory into the MFMA ------------
 // A problem with fewer 64x64 tiles than CUs (the temporal transformer at a few hundred tokens, the similarity heads) is
 // latency-bound in the kernel below: each of its few workgroups walks K in 16-deep steps of 16 MFMAs behind an LDS round trip
-// and a barrier.  Here a wave owns a 16 x 32 tile (8 MFMAs per step, 8x as many workgroups), and because the k index an MFMA
-// lane group consumes is free to choose, lane (r = lane & 15, kg = lane >> 4) simply takes k = k0 + 4 kg + s in sub-step s:
-// for a k-contiguous operand that is one 16-byte load of its own row, for a row-contiguous one four coalesced 4-byte loads.
-// No LDS, no barrier; the loads of the next two steps are in flight while a step computes.
-__device__ __forceinline__ f4 small_frag(const float* P, long sr, long sk, int R, int K, int row, int k, bool vec) {
-  f4 v = {0.f, 0.f, 0.f, 0.f};
-  const float* p = P + (long)row * sr + (long)k * sk;           // row already clamped into [0, R)
-  if (sk == 1 && vec && k + 3 < K) return *reinterpret_cast<const f4*>(p);
+// and a barrier.  Here a workgroup owns a 16 x 32 tile and its four waves split K between them (wave w takes the 16-deep
+// steps w, w + 4, ...), so the dependent MFMA chain is K/4 long and there are 4x as many waves to hide the load latency;
+// the partial tiles meet in LDS in a fixed order.  Because the k index an MFMA lane group consumes is free to choose, lane
+// (r = lane & 15, kg = lane >> 4) simply takes k = k0 + 4 kg + s in sub-step s: for a k-contiguous operand that is one
+// 16-byte load of its own row, for a row-contiguous one four coalesced 4-byte loads.  No LDS or barrier inside the K loop;
+// the loads of the next PD steps are in flight while a step computes.
+// Every load is unconditional (k clamped into the row) and the zeroing of k >= K happens when a fragment is consumed: a
+// branch around a load would make the compiler wait for all loads in flight at the join and serialise the pipeline.
+template <bool VEC>
+__device__ __forceinline__ f4 small_frag(const float* rowp, long sk, int K, int k) {
+  if constexpr (VEC) {                                           // k-contiguous, 16-byte aligned rows, K % 4 == 0
+    return *reinterpret_cast<const f4*>(rowp + (k < K ? k : 0));
+  } else {
+    f4 v;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) if (k + s < K) v[s] = p[(long)s * sk];
+    for (int s = 0; s < 4; ++s) v[s] = rowp[(long)min(k + s, K - 1) * sk];
+    return v;
+  }
+}
+
+__device__ __forceinline__ f4 zero_past(f4 v, int k, int K) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) v[s] = k + s < K ? v[s] : 0.f;
   return v;
 }
 
-__global__ __launch_bounds__(64) void gemm_f32_small_kernel(G32 p) {
-  const int lane = threadIdx.x;
+template <bool AV, bool BV>
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(G32 p) {
+  __shared__ f4 red[4][2][64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntn = (p.N + 31) / 32;
   const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
   const int m0 = tm * 16, n0 = tn * 32;
   const int r = lane & 15, kg = lane >> 4;
-  const int ma = min(m0 + r, p.M - 1), nb0 = min(n0 + r, p.N - 1), nb1 = min(n0 + 16 + r, p.N - 1);
+  const float* pa = p.A + (long)min(m0 + r, p.M - 1) * p.sam;
+  const float* pb0 = p.B + (long)min(n0 + r, p.N - 1) * p.sbn;
+  const float* pb1 = p.B + (long)min(n0 + 16 + r, p.N - 1) * p.sbn;
   f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-  constexpr int PD = 3;
+  constexpr int PD = 4;
   const int nkt = (p.K + 15) / 16;
+  const int nj = nkt > w ? (nkt - w + 3) / 4 : 0;               // this wave's steps: kt = w + 4 j
   f4 fa[PD], fb0[PD], fb1[PD];
-  auto fetch = [&](int kt, f4& a, f4& b0, f4& b1) {
-    const int k = kt * 16 + 4 * kg;
-    a = small_frag(p.A, p.sam, p.sak, p.M, p.K, ma, k, p.avec);
-    b0 = small_frag(p.B, p.sbn, p.sbk, p.N, p.K, nb0, k, p.bvec);
-    b1 = small_frag(p.B, p.sbn, p.sbk, p.N, p.K, nb1, k, p.bvec);
+  auto fetch = [&](int j, f4& a, f4& b0, f4& b1) {
+    const int k = (w + 4 * j) * 16 + 4 * kg;
+    a = small_frag<AV>(pa, p.sak, p.K, k);
+    b0 = small_frag<BV>(pb0, p.sbk, p.K, k);
+    b1 = small_frag<BV>(pb1, p.sbk, p.K, k);
   };
 #pragma unroll
-  for (int s = 0; s < PD; ++s) fetch(s, fa[s], fb0[s], fb1[s]);      // past K: zeros
-  auto step = [&](int kt, f4& a, f4& b0, f4& b1) {
-    const f4 ca = a, cb0 = b0, cb1 = b1;
-    fetch(kt + PD, a, b0, b1);
+  for (int s = 0; s < PD; ++s) fetch(s, fa[s], fb0[s], fb1[s]);
+  auto step = [&](int j, f4& a, f4& b0, f4& b1) {
+    const int k = (w + 4 * j) * 16 + 4 * kg;
+    const f4 ca = zero_past(a, k, p.K), cb0 = zero_past(b0, k, p.K), cb1 = zero_past(b1, k, p.K);
+    fetch(j + PD, a, b0, b1);
+    __builtin_amdgcn_sched_barrier(0);     // keep the refill ahead of this step's MFMAs (the scheduler would sink it to the loop end)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb0[s], ca[s], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb1[s], ca[s], acc[1], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
-  for (int kt = 0; kt < nkt; kt += PD) {
-    step(kt, fa[0], fb0[0], fb1[0]);
-    if (kt + 1 < nkt) step(kt + 1, fa[1], fb0[1], fb1[1]);
-    if (kt + 2 < nkt) step(kt + 2, fa[2], fb0[2], fb1[2]);
+  for (int j = 0; j < nj; j += PD) {       // no branches inside: steps past nj multiply zeros (k >= K), and the counted waits stay exact
+    step(j, fa[0], fb0[0], fb1[0]);
+    step(j + 1, fa[1], fb0[1], fb1[1]);
+    step(j + 2, fa[2], fb0[2], fb1[2]);
+    step(j + 3, fa[3], fb0[3], fb1[3]);
   }
-  store_tile16(p, acc[0], m0 + r, n0 + 4 * kg);
-  store_tile16(p, acc[1], m0 + r, n0 + 16 + 4 * kg);
+  red[w][0][lane] = acc[0];
+  red[w][1][lane] = acc[1];
+  __syncthreads();
+  if (w < 2) {
+    const f4 t = (red[0][w][lane] + red[1][w][lane]) + (red[2][w][lane] + red[3][w][lane]);
+    store_tile16(p, t, m0 + r, n0 + 16 * w + 4 * kg);
+  }
 }
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
@@ -281,7 +309,10 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
   // (weight gradients): their fragments cost four 4-byte loads each there, and the LDS kernel is faster (measured)
   if (blocks < num_cu && (sak == 1 || sbk == 1)) {
     long small = (long)((M + 15) / 16) * ((N + 31) / 32);
-    hipLaunchKernelGGL(gemm_f32_small_kernel, dim3((unsigned)small), dim3(64), 0, stream, p);
+    const bool av = sak == 1 && p.avec && !(K & 3), bv = sbk == 1 && p.bvec && !(K & 3);
+    auto k = av ? (bv ? gemm_f32_small_kernel<true, true> : gemm_f32_small_kernel<true, false>)
+                : (bv ? gemm_f32_small_kernel<false, true> : gemm_f32_small_kernel<false, false>);
+    hipLaunchKernelGGL(k, dim3((unsigned)small), dim3(256), 0, stream, p);
     return hmmc_launch_status();
   }
   hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);

@@ -42,18 +42,19 @@ def close(a, b, atol, rtol=0.0, what=""):
 
 def test_gemm_f32_all_orientations():
     g = torch.Generator().manual_seed(0)
-    for (M, N, K) in [(64, 64, 16), (100, 36, 52), (256, 3328, 512), (3328, 512, 256)]:
+    for (M, N, K) in [(64, 64, 16), (100, 36, 52), (50, 40, 203), (384, 512, 2048), (256, 3328, 512), (3328, 512, 256)]:
         a = torch.randn(M, K, generator=g).to(DEV)
         b = torch.randn(N, K, generator=g).to(DEV)
         ref = a.double() @ b.double().t()
+        tol = 1e-4 * max(1.0, K / 512)                                           # fp32 accumulation error grows with K
         c = ops.gemm_f32(a, b, M, N, K, (K, 1), (1, K))                          # x W^T
-        close(c, ref, 1e-4, 1e-5, "kk")
+        close(c, ref, tol, 1e-5, "kk")
         bt = b.t().contiguous()                                                   # [K, N]
         c = ops.gemm_f32(a, bt, M, N, K, (K, 1), (N, 1), alpha=2.0)              # dy W
-        close(c, 2 * ref, 2e-4, 1e-5, "kn")
+        close(c, 2 * ref, 2 * tol, 1e-5, "kn")
         at = a.t().contiguous()                                                   # [K, M]
         c = ops.gemm_f32(at, bt, M, N, K, (1, M), (N, 1))                        # dy^T x
-        close(c, ref, 1e-4, 1e-5, "tn")
+        close(c, ref, tol, 1e-5, "tn")
     x, w, bias, res = torch.randn(77, 512).to(DEV), torch.randn(2048, 512).to(DEV) * 0.05, torch.randn(2048).to(DEV), None
     gq, h = ops.linear_f32(x, w, bias=bias, epilogue=ops.EPI_QGELU, want_aux=True)
     href = x @ w.t() + bias
