@@ -305,9 +305,10 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? n : 256;
   }();
-  // fewer 64x64 tiles than CUs: latency-bound, take the one-wave 16x32 kernel - unless both operands are row-contiguous
-  // (weight gradients): their fragments cost four 4-byte loads each there, and the LDS kernel is faster (measured)
-  if (blocks < num_cu && (sak == 1 || sbk == 1)) {
+  // fewer 64x64 tiles than CUs: latency-bound, take the split-K 16x32 kernel.  With both operands row-contiguous (weight
+  // gradients) its fragments cost four 4-byte loads each, and it only wins below half a wave of tiles (measured: 512x512
+  // outputs 104 -> 33 us at K = 3072, 17 -> 9 us at K = 384; 1536x512 outputs 18 -> 21 us at K = 384)
+  if (blocks < num_cu && (sak == 1 || sbk == 1 || blocks * 2 <= num_cu)) {
     long small = (long)((M + 15) / 16) * ((N + 31) / 32);
     const bool av = sak == 1 && p.avec && !(K & 3), bv = sbk == 1 && p.bvec && !(K & 3);
     auto k = av ? (bv ? gemm_f32_small_kernel<true, true> : gemm_f32_small_kernel<true, false>)

@@ -340,25 +340,40 @@ class MocoLossFn(torch.autograd.Function):
 
 class MlmHeadFn(torch.autograd.Function):
     """BertLMPredictionHead + cross-entropy with ignore_index -100 (modules/module_cross.py:308-357,
-    modules/modeling.py:171-179): dense, erf-GELU, TF-LayerNorm(1e-12), decoder to the vocabulary, mean CE."""
+    modules/modeling.py:171-179): dense, erf-GELU, TF-LayerNorm(1e-12), decoder to the vocabulary, mean CE.
+
+    The reference runs the head over all b*L positions and lets the loss ignore the ~85 % whose label is -100; neither
+    the loss nor any gradient depends on those rows, so the head (a [rows, 512] x [512, 49408] fp32 GEMM and its two
+    backward GEMMs) is evaluated on the labelled rows only.  Their number sizes the launches, hence one host read of the
+    row list per call (torch.nonzero)."""
 
     @staticmethod
     def forward(ctx, hidden, labels, dw, db, lnw, lnb, decw, decb):
-        x = hidden.contiguous().view(-1, hidden.shape[-1])
+        x_all = hidden.contiguous().view(-1, hidden.shape[-1])
         labels = labels.contiguous().view(-1)
+        rows = torch.nonzero(labels >= 0).view(-1)
+        ctx.shape, ctx.n = hidden.shape, int(rows.numel())
+        if ctx.n == 0:                       # nothing masked: the loss is 0 (sum over no rows / max(count, 1)), all gradients 0
+            ctx.save_for_backward(dw, lnw, decw, decb)
+            return x_all.new_zeros(())
+        x = x_all.index_select(0, rows)
+        lab = labels.index_select(0, rows)
         a = ops.linear_f32(x, dw, bias=db)
         g = ops.gelu_erf_fwd(a)
         t, mean, rstd = ops.layernorm_fwd(g, lnw, lnb, 1e-12)
         logits = ops.linear_f32(t, decw, bias=decb)
-        loss_sum, lse, count = ops.ce_fwd(logits, labels)
-        ctx.save_for_backward(x, labels, dw, lnw, decw, a, g, t, mean, rstd, logits, lse, count)
-        ctx.shape = hidden.shape
+        loss_sum, lse, count = ops.ce_fwd(logits, lab)
+        ctx.save_for_backward(x, lab, rows, dw, lnw, decw, a, g, t, mean, rstd, logits, lse, count)
         return loss_sum / count.clamp(min=1.0)[0]
 
     @staticmethod
     def backward(ctx, gout):
-        x, labels, dw, lnw, decw, a, g, t, mean, rstd, logits, lse, count = ctx.saved_tensors
-        dlogits = ops.ce_bwd_(logits, labels, lse, gout, count)
+        if ctx.n == 0:
+            dw, lnw, decw, decb = ctx.saved_tensors
+            return (dw.new_zeros(ctx.shape), None, torch.zeros_like(dw), dw.new_zeros(dw.shape[0]), torch.zeros_like(lnw),
+                    torch.zeros_like(lnw), torch.zeros_like(decw), torch.zeros_like(decb))
+        x, lab, rows, dw, lnw, decw, a, g, t, mean, rstd, logits, lse, count = ctx.saved_tensors
+        dlogits = ops.ce_bwd_(logits, lab, lse, gout, count)
         d_decw = ops.wgrad_f32(dlogits, t)
         d_decb = ops.colsum(dlogits)
         dt = ops.dgrad_f32(dlogits, decw)
@@ -366,5 +381,6 @@ class MlmHeadFn(torch.autograd.Function):
         da = ops.gelu_erf_bwd(a, dg)
         d_dw = ops.wgrad_f32(da, x)
         d_db = ops.colsum(da)
-        dx = ops.dgrad_f32(da, dw)
+        dx_rows = ops.dgrad_f32(da, dw)
+        dx = dx_rows.new_zeros(ctx.shape[:-1].numel(), ctx.shape[-1]).index_copy_(0, rows, dx_rows)
         return dx.view(ctx.shape), None, d_dw, d_db, d_lnw, d_lnb, d_decw, d_decb

@@ -76,6 +76,17 @@ def test_mlm_head_fn_vs_oracle():
     close(P["cls.decoder.weight"].grad, sdo["cls.decoder.weight"].grad, 1e-6, 2e-3, "ddecoder")
     close(P["cls.bias"].grad, sdo["cls.bias"].grad, 1e-6, 2e-3, "dbias")
     close(P["cls.transform.dense.weight"].grad, sdo["cls.transform.dense.weight"].grad, 1e-6, 2e-3, "ddense")
+    # no labelled position at all: zero loss and zero gradients (the head is evaluated on labelled rows only)
+    h0 = hidden.to(DEV).requires_grad_()
+    for q in P.values():
+        q.grad = None
+    loss0 = Fn.MlmHeadFn.apply(h0, torch.full((3, 20), -100, dtype=torch.long, device=DEV), P["cls.transform.dense.weight"],
+                               P["cls.transform.dense.bias"], P["cls.transform.LayerNorm.weight"],
+                               P["cls.transform.LayerNorm.bias"], P["cls.decoder.weight"], P["cls.bias"])
+    loss0.backward()
+    assert float(loss0) == 0.0 and float(h0.grad.abs().max()) == 0.0
+    assert all(q.grad is None or float(q.grad.abs().max()) == 0.0 for q in P.values())
+    assert P["cls.decoder.weight"].grad is not None and P["cls.transform.dense.weight"].grad is not None
 
 
 def test_pretrain_steps_vs_reference_golden():
