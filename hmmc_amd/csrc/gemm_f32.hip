@@ -25,76 +25,48 @@ struct G32 {
 
 __device__ __forceinline__ float qgelu32(float h) { return h / (1.0f + __expf(-1.702f * h)); }
 
-// load this thread's 4 elements of a 64 x 16 operand tile (rows r0.., k-range k0..) into regs
-__device__ __forceinline__ f4 load_op(const float* P, long sr, long sk, int R, int K, int r0, int k0, int tid, bool vec) {
-  f4 v = {0.f, 0.f, 0.f, 0.f};
-  if (sk == 1) {            // k contiguous: thread -> (row = tid/4, k = 4*(tid%4))
-    int r = r0 + (tid >> 2), k = k0 + (tid & 3) * 4;
-    if (r < R) {
-      const float* p = P + (long)r * sr + k;
-      if (vec && k + 3 < K) v = *reinterpret_cast<const f4*>(p);
-      else {
+// ---- operand staging of the 64x64x16 kernel ---------------------------------------------------------------------------
+// A thread owns 4 elements of a 64 x 16 operand tile per K-step.  MODE 0: k-contiguous rows read with one 16-byte load
+// (thread -> row tid/4, k 4*(tid%4)..+3; needs 16-byte aligned rows and K % 4 == 0); MODE 1: row-contiguous read with one
+// 16-byte load (thread -> k tid/16, rows 4*(tid%16)..+3; needs R % 4 == 0); MODE 2: any unit-stride orientation, four 4-byte
+// loads.  Every load is unconditional with its row and k clamped into the operand: rows past R feed output rows that are
+// never stored, and k >= K is zeroed when the registers are written to LDS - a branch around a load makes the compiler
+// drain every load in flight at the join, which serialises the prefetch pipeline.
+enum { OP_KVEC = 0, OP_RVEC = 1, OP_SCALAR = 2 };
+
+template <int MODE>
+__device__ __forceinline__ f4 fetch_op(const float* P, long sr, long sk, int R, int K, int r0, int k0, int tid) {
+  if constexpr (MODE == OP_KVEC) {
+    const int r = min(r0 + (tid >> 2), R - 1), k = k0 + (tid & 3) * 4;
+    return *reinterpret_cast<const f4*>(P + (long)r * sr + (k < K ? k : 0));
+  } else if constexpr (MODE == OP_RVEC) {
+    const int k = min(k0 + (tid >> 4), K - 1), r = r0 + (tid & 15) * 4;
+    return *reinterpret_cast<const f4*>(P + (long)k * sk + (r < R ? r : 0));
+  } else {
+    const bool kc = sk == 1;
+    f4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (k + j < K) v[j] = p[j];
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int r = kc ? r0 + (tid >> 2) : r0 + (tid & 15) * 4 + j;
+      const int k = kc ? k0 + (tid & 3) * 4 + j : k0 + (tid >> 4);
+      v[j] = P[(long)min(r, R - 1) * sr + (long)min(k, K - 1) * sk];
     }
-  } else {                  // row contiguous: thread -> (k = tid/16, row = 4*(tid%16))
-    int k = k0 + (tid >> 4), r = r0 + (tid & 15) * 4;
-    if (k < K) {
-      const float* p = P + (long)k * sk + r;
-      if (vec && r + 3 < R) v = *reinterpret_cast<const f4*>(p);
-      else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (r + j < R) v[j] = p[j];
-      }
-    }
+    return v;
   }
-  return v;
 }
 
-// Loop-invariant part of load_op: the thread's source pointer for K-step 0, its per-step advance, and whether its
-// 4 elements can be fetched as one aligned 16-byte load for every K-step that lies fully inside K (row / alignment
-// conditions do not depend on k).  Steps that reach past K go through load_op.
-struct OpLoader {
-  const float* ptr; long adv; bool vec4, any;
-};
-__device__ __forceinline__ OpLoader make_loader(const float* P, long sr, long sk, int R, int r0, int tid, bool vec) {
-  OpLoader L;
-  if (sk == 1) {
-    int r = r0 + (tid >> 2);
-    L.ptr = P + (long)r * sr + (tid & 3) * 4; L.adv = TK; L.any = r < R; L.vec4 = vec && L.any;
+// write them into the LDS image [k][row], zeroing k >= K
+template <int MODE>
+__device__ __forceinline__ void store_op(float* S, f4 v, long sk, int K, int k0, int tid) {
+  const bool kc = MODE == OP_KVEC || (MODE == OP_SCALAR && sk == 1);
+  if (kc) {
+    const int r = tid >> 2, k = (tid & 3) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) S[(k + j) * LDS_LD + r] = k0 + k + j < K ? v[j] : 0.f;
   } else {
-    int r = r0 + (tid & 15) * 4;
-    L.ptr = P + (long)(tid >> 4) * sk + r; L.adv = (long)TK * sk; L.any = r < R; L.vec4 = vec && r + 3 < R;
-  }
-  return L;
-}
-__device__ __forceinline__ f4 load_inner(const OpLoader& L, long sk, int R, int r0, int kt, int tid) {
-  const float* p = L.ptr + (long)kt * L.adv;
-  if (L.vec4) return *reinterpret_cast<const f4*>(p);
-  f4 v = {0.f, 0.f, 0.f, 0.f};
-  if (L.any) {
-    if (sk == 1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = p[j];
-    } else {
-      int r = r0 + (tid & 15) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) if (r + j < R) v[j] = p[j];
-    }
-  }
-  return v;
-}
-
-// write them into the LDS image [k][row]
-__device__ __forceinline__ void store_op(float* S, f4 v, bool kcontig, int tid) {
-  if (kcontig) {
-    int r = tid >> 2, k = (tid & 3) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) S[(k + j) * LDS_LD + r] = v[j];
-  } else {
-    int k = tid >> 4, r = (tid & 15) * 4;
-    *reinterpret_cast<f4*>(S + k * LDS_LD + r) = v;
+    const int k = tid >> 4, r = (tid & 15) * 4;
+    const bool in = k0 + k < K;
+    *reinterpret_cast<f4*>(S + k * LDS_LD + r) = f4{in ? v[0] : 0.f, in ? v[1] : 0.f, in ? v[2] : 0.f, in ? v[3] : 0.f};
   }
 }
 
@@ -206,6 +178,7 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(G32 p) {
   }
 }
 
+template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
   __shared__ __attribute__((aligned(16))) float sA[2][TK * LDS_LD];
   __shared__ __attribute__((aligned(16))) float sB[2][TK * LDS_LD];
@@ -214,7 +187,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
   const int ntn = (p.N + TN - 1) / TN;
   const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
   const int m0 = tm * TM, n0 = tn * TN;
-  const bool ak = p.sak == 1, bk = p.sbk == 1;
 
   f4 acc[2][2];
 #pragma unroll
@@ -222,54 +194,76 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-  // Register-staged pipeline, PD K-steps deep: the global loads of step kt + PD are issued before step kt is computed and
-  // reach LDS one step before they are needed, so a lone workgroup on a CU (small M, or K-long weight gradients with
-  // few output tiles) still has PD loads in flight instead of waiting out one full memory latency per 16-deep K-step.
-  constexpr int PD = 3;
+  // Two pipelines.  Global -> registers runs PD K-steps ahead (a step is 0.2 us of MFMA, a miss to HBM 1.5 us), so a lone
+  // workgroup on a CU keeps PD loads in flight.  LDS -> fragment registers runs one step ahead: the 16 fragment words of
+  // step kt + 1 are read while the MFMAs of step kt execute, so neither the LDS latency nor the staging stores sit between
+  // two steps' MFMAs; one barrier per step.  The loop body has no branches: the steps of the last round that lie past K
+  // multiply zeros (store_op zeroes k >= K).
+  constexpr int PD = 8;
   const int nkt = (p.K + TK - 1) / TK;
-  const int nfull = p.K / TK;                     // K-steps that lie fully inside K: no k bounds checks
-  const OpLoader LA = make_loader(p.A, p.sam, p.sak, p.M, m0, tid, p.avec);
-  const OpLoader LB = make_loader(p.B, p.sbn, p.sbk, p.N, n0, tid, p.bvec);
-  auto fetch_a = [&](int kt) { return kt < nfull ? load_inner(LA, p.sak, p.M, m0, kt, tid)
-                                                 : load_op(p.A, p.sam, p.sak, p.M, p.K, m0, kt * TK, tid, p.avec); };   // past K: zeros
-  auto fetch_b = [&](int kt) { return kt < nfull ? load_inner(LB, p.sbk, p.N, n0, kt, tid)
-                                                 : load_op(p.B, p.sbn, p.sbk, p.N, p.K, n0, kt * TK, tid, p.bvec); };
   f4 ra[PD], rb[PD];
 #pragma unroll
-  for (int s = 0; s < PD; ++s) { ra[s] = fetch_a(s); rb[s] = fetch_b(s); }
-  store_op(sA[0], ra[0], ak, tid);
-  store_op(sB[0], rb[0], bk, tid);
-  __syncthreads();
-  auto step = [&](int kt, f4& ra_next, f4& rb_next, f4& ra_slot, f4& rb_slot) {
-    // ra_slot held step kt (already in LDS): refill it with step kt + PD; ra_next holds step kt + 1
-    const int cur = kt & 1;
-    ra_slot = fetch_a(kt + PD);
-    rb_slot = fetch_b(kt + PD);
-    const float* a = sA[cur];
-    const float* b = sB[cur];
+  for (int s = 0; s < PD; ++s) {
+    ra[s] = fetch_op<AMODE>(p.A, p.sam, p.sak, p.M, p.K, m0, s * TK, tid);
+    rb[s] = fetch_op<BMODE>(p.B, p.sbn, p.sbk, p.N, p.K, n0, s * TK, tid);
+  }
+  struct Frags { float a[TK / 4][2], b[TK / 4][2]; };
+  auto read_frags = [&](int buf, Frags& f) {
+    const float* a = sA[buf];
+    const float* b = sB[buf];
 #pragma unroll
-    for (int kk = 0; kk < TK; kk += 4) {
-      float af[2], bf[2];
+    for (int kk = 0; kk < TK / 4; ++kk)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[i] = a[(kk + (lane >> 4)) * LDS_LD + wm * 32 + i * 16 + (lane & 15)];
-        bf[i] = b[(kk + (lane >> 4)) * LDS_LD + wn * 32 + i * 16 + (lane & 15)];
+        f.a[kk][i] = a[(4 * kk + (lane >> 4)) * LDS_LD + wm * 32 + i * 16 + (lane & 15)];
+        f.b[kk][i] = b[(4 * kk + (lane >> 4)) * LDS_LD + wn * 32 + i * 16 + (lane & 15)];
       }
+  };
+  Frags f0, f1;
+  store_op<AMODE>(sA[0], ra[0], p.sak, p.K, 0, tid);
+  store_op<BMODE>(sB[0], rb[0], p.sbk, p.K, 0, tid);
+  store_op<AMODE>(sA[1], ra[1], p.sak, p.K, TK, tid);
+  store_op<BMODE>(sB[1], rb[1], p.sbk, p.K, TK, tid);
+  ra[0] = fetch_op<AMODE>(p.A, p.sam, p.sak, p.M, p.K, m0, PD * TK, tid);
+  rb[0] = fetch_op<BMODE>(p.B, p.sbn, p.sbk, p.N, p.K, n0, PD * TK, tid);
+  ra[1] = fetch_op<AMODE>(p.A, p.sam, p.sak, p.M, p.K, m0, (PD + 1) * TK, tid);
+  rb[1] = fetch_op<BMODE>(p.B, p.sbn, p.sbk, p.N, p.K, n0, (PD + 1) * TK, tid);
+  __syncthreads();
+  read_frags(0, f0);
+  __syncthreads();                                 // step 0 overwrites buffer 0: every wave must hold its fragments of step 0 first
+  // step kt: fragments of kt are in `cur`; read those of kt + 1 from buffer (kt + 1) & 1, multiply, then overwrite buffer kt & 1
+  // (every wave has its fragments of step kt in registers since the barrier that ended step kt - 1) with step kt + 2 from
+  // register slot (kt + 2) % PD and refill that slot with step kt + 2 + PD
+  // A wave issues in order, so whatever sits between the last MFMA of one step and the first of the next is exposed: the
+  // LDS reads, the staging stores (which wait for the global data) and the refill are therefore placed between the four
+  // 4-MFMA groups of the step, where they issue in the shadow of the 32-cycle MFMAs.
+  auto mfma4 = [&](const Frags& f, int kk) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nkt) {
-      store_op(sA[cur ^ 1], ra_next, ak, tid);
-      store_op(sB[cur ^ 1], rb_next, bk, tid);
-    }
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[kk][j], f.a[kk][i], acc[i][j], 0, 0, 0);
+  };
+  auto step = [&](int kt, const Frags& cur, Frags& nxt, f4& sa, f4& sb) {
+    mfma4(cur, 0);
+    read_frags((kt + 1) & 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma4(cur, 1);
+    store_op<AMODE>(sA[kt & 1], sa, p.sak, p.K, (kt + 2) * TK, tid);
+    store_op<BMODE>(sB[kt & 1], sb, p.sbk, p.K, (kt + 2) * TK, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma4(cur, 2);
+    sa = fetch_op<AMODE>(p.A, p.sam, p.sak, p.M, p.K, m0, (kt + 2 + PD) * TK, tid);
+    sb = fetch_op<BMODE>(p.B, p.sbn, p.sbk, p.N, p.K, n0, (kt + 2 + PD) * TK, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma4(cur, 3);
     __syncthreads();
   };
-  for (int kt = 0; kt < nkt; kt += PD) {          // slots rotate with period PD: static register indices
-    step(kt, ra[1], rb[1], ra[0], rb[0]);
-    if (kt + 1 < nkt) step(kt + 1, ra[2], rb[2], ra[1], rb[1]);
-    if (kt + 2 < nkt) step(kt + 2, ra[0], rb[0], ra[2], rb[2]);
+  for (int kt = 0; kt < nkt; kt += PD) {          // slots and buffers rotate with period PD (even): static register indices
+#pragma unroll
+    for (int s = 0; s < PD; s += 2) {
+      step(kt + s, f0, f1, ra[(s + 2) % PD], rb[(s + 2) % PD]);
+      step(kt + s + 1, f1, f0, ra[(s + 3) % PD], rb[(s + 3) % PD]);
+    }
   }
   // lane owns C[m = .. + (lane & 15)][n = .. + 4*(lane >> 4) + r]
 #pragma unroll
@@ -277,6 +271,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       store_tile16(p, acc[i][j], m0 + wm * 32 + i * 16 + (lane & 15), n0 + wn * 32 + j * 16 + 4 * (lane >> 4));
+}
+
+template <int AMODE>
+void launch_f32(int bmode, dim3 grid, hipStream_t stream, const G32& p) {
+  switch (bmode) {
+    case OP_KVEC: hipLaunchKernelGGL((gemm_f32_kernel<AMODE, OP_KVEC>), grid, dim3(256), 0, stream, p); break;
+    case OP_RVEC: hipLaunchKernelGGL((gemm_f32_kernel<AMODE, OP_RVEC>), grid, dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL((gemm_f32_kernel<AMODE, OP_SCALAR>), grid, dim3(256), 0, stream, p); break;
+  }
 }
 
 }  // namespace
@@ -305,10 +308,15 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? n : 256;
   }();
-  // fewer 64x64 tiles than CUs: latency-bound, take the split-K 16x32 kernel.  With both operands row-contiguous (weight
-  // gradients) its fragments cost four 4-byte loads each, and it only wins below half a wave of tiles (measured: 512x512
-  // outputs 104 -> 33 us at K = 3072, 17 -> 9 us at K = 384; 1536x512 outputs 18 -> 21 us at K = 384)
-  if (blocks < num_cu && (sak == 1 || sbk == 1 || blocks * 2 <= num_cu)) {
+  // Two kernels.  The 64x64 LDS kernel runs one 16-deep K-step per ~0.4 us while a workgroup is alone on its CU (0.2 us of
+  // MFMA plus the in-order issue of its staging and the barrier) and ~0.6x that per further co-resident workgroup, so a
+  // problem with few tiles is bound by the length of K; the split-K 16x32 kernel has no such chain but re-reads its operands
+  // from L2 for every 16x32 tile (0.19 B/flop; both operands k-contiguous cost more because a 16-byte load then touches 16
+  // rows).  Estimated times in us (fitted to measurements at 96..3072 rows of the temporal-transformer shapes) pick one.
+  const double mnk = (double)M * N * K;
+  const double t_small = 3.0 + mnk * ((sak == 1 && sbk == 1) ? 6.0e-8 : 3.9e-8);
+  const double t_tiled = 3.0 + (K / 16.0) * 0.40 * (0.4 + 0.6 * (double)((blocks + num_cu - 1) / num_cu));
+  if (t_small < t_tiled) {
     long small = (long)((M + 15) / 16) * ((N + 31) / 32);
     const bool av = sak == 1 && p.avec && !(K & 3), bv = sbk == 1 && p.bvec && !(K & 3);
     auto k = av ? (bv ? gemm_f32_small_kernel<true, true> : gemm_f32_small_kernel<true, false>)
@@ -316,6 +324,13 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
     hipLaunchKernelGGL(k, dim3((unsigned)small), dim3(256), 0, stream, p);
     return hmmc_launch_status();
   }
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  const int amode = !p.avec ? OP_SCALAR : sak == 1 ? ((K & 3) ? OP_SCALAR : OP_KVEC) : ((M & 3) ? OP_SCALAR : OP_RVEC);
+  const int bmode = !p.bvec ? OP_SCALAR : sbk == 1 ? ((K & 3) ? OP_SCALAR : OP_KVEC) : ((N & 3) ? OP_SCALAR : OP_RVEC);
+  const dim3 grid((unsigned)blocks);
+  switch (amode) {
+    case OP_KVEC: launch_f32<OP_KVEC>(bmode, grid, stream, p); break;
+    case OP_RVEC: launch_f32<OP_RVEC>(bmode, grid, stream, p); break;
+    default: launch_f32<OP_SCALAR>(bmode, grid, stream, p); break;
+  }
   return hmmc_launch_status();
 }

@@ -8,7 +8,7 @@ lib = _lib.load()
 g = torch.Generator(device="cuda").manual_seed(0)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 tot = {}
-for T in (3072, 384, 96):
+for T in [int(t) for t in os.environ.get("TS", "3072,384,96").split(",")]:
     for name, M, N, K, lay in (("qkv", T, 1536, 512, "kk"), ("out", T, 512, 512, "kk"), ("fc", T, 2048, 512, "kk"), ("proj", T, 512, 2048, "kk"),
                                ("dqkv", T, 512, 1536, "km"), ("dout", T, 512, 512, "km"), ("dproj", T, 2048, 512, "km"), ("dfc", T, 512, 2048, "km"),
                                ("wqkv", 1536, 512, T, "mm"), ("wfc", 2048, 512, T, "mm"), ("wproj", 512, 2048, T, "mm"), ("wout", 512, 512, T, "mm")):
