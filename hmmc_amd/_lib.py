@@ -70,8 +70,8 @@ SIGNATURES = {
     "hmmc_tower_act_bytes": ("liiiii", "z"),
     "hmmc_tower_bwd_scratch_bytes": ("lii", "z"),
     "hmmc_tower_workspace_bytes": ("liii", "z"),
-    "hmmc_tower_fwd": ("ppppiiiiiiifipzp", "i"),
-    "hmmc_tower_bwd": ("pppppppiiiiiiipzpp", "i"),
+    "hmmc_tower_fwd": ("ppppiiiiiiifiipzp", "i"),
+    "hmmc_tower_bwd": ("pppppppiiiiiiiipzpp", "i"),
 }
 
 ERRORS = {-1: "invalid argument", -2: "unsupported shape/alignment", -3: "workspace too small", -4: "kernel launch failed"}

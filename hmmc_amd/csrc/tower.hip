@@ -82,14 +82,15 @@ inline int dgrad(bool f32, const void* dy, const void* w, void* dx, int M, int N
   return hmmc_gemm_f16(dy, w, dx, M, Kp, Np, Np, Kp, Kp, 1, 0, nullptr, nullptr, nullptr, aux_in, epi | (csum ? EPI_COLSUM : 0),
                        csum, csum_bytes, s);
 }
-// dW[N',K'] = dy[T,N']^T x[T,K']
-inline int wgrad(bool f32, const void* dy, const void* x, void* dw, int T, int Np, int Kp, void* ws, size_t wsb, hipStream_t s) {
+// dW[N',K'] = dy[T,N']^T x[T,K'];  ldy / ldx: row strides of dy and x (0 = dense)
+inline int wgrad(bool f32, const void* dy, const void* x, void* dw, int T, int Np, int Kp, void* ws, size_t wsb, hipStream_t s,
+                 int ldy = 0, int ldx = 0) {
   if (f32)
     return hmmc_gemm_f32((const float*)dy, (const float*)x, (float*)dw, Np, Kp, T, 1, Np, Kp, 1, Kp, 1.0f, nullptr, nullptr,
                          nullptr, nullptr, 0, s);
   size_t need = hmmc_gemm_f16_workspace(Np, Kp, T);
-  return hmmc_gemm_f16(dy, x, dw, Np, Kp, T, Np, Kp, Kp, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, need <= wsb ? ws : nullptr,
-                       need <= wsb ? wsb : 0, s);
+  return hmmc_gemm_f16(dy, x, dw, Np, Kp, T, ldy ? ldy : Np, ldx ? ldx : Kp, Kp, 0, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                       need <= wsb ? ws : nullptr, need <= wsb ? wsb : 0, s);
 }
 
 #define CK(call) do { int rc_ = (call); if (rc_ != 0) return rc_; } while (0)
@@ -150,10 +151,16 @@ extern "C" size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int f
 }
 
 // y = tower(x).  keep_acts: acts holds nlayers slabs (training); otherwise one slab is reused (key encoders, eval).
+//
+// lead_only (fp16 towers): the caller consumes only token 0 of every sequence of y (the ViT's class token: ln_post and proj
+// are applied to that row alone, modules/module_cross.py:228-230).  Everything of the LAST block after its attention is
+// per-token, so out_proj, ln_2 and the MLP run on the nseq leading rows only (read and written in place at stride L*D);
+// the other rows of y are left undefined.  hmmc_tower_bwd with the same flag reads only those rows of dy.
 extern "C" int hmmc_tower_fwd(const void* x, void* y, const void* const* params, void* acts, int keep_acts, int nseq, int L,
-                              int heads, int D, int nlayers, int causal, float eps, int fp32, void* workspace,
+                              int heads, int D, int nlayers, int causal, float eps, int fp32, int lead_only, void* workspace,
                               size_t ws_bytes, hipStream_t s) {
   if (!x || !y || !params || !acts || nseq <= 0 || L <= 0 || heads <= 0 || nlayers <= 0 || D != heads * 64) return HMMC_ERR_ARG;
+  if (lead_only && fp32) return HMMC_ERR_UNSUPPORTED;
   const bool f32 = fp32 != 0;
   const int es = f32 ? 4 : 2, dt = f32 ? 1 : 0;
   const long T = (long)nseq * L;
@@ -167,17 +174,29 @@ extern "C" int hmmc_tower_fwd(const void* x, void* y, const void* const* params,
     CK(linear(f32, a.ln1, P[2], a.qkv, (int)T, 3 * D, D, P[3], nullptr, nullptr, 0, workspace, ws_bytes, s));
     if (f32) CK(hmmc_temporal_attention_fwd((const float*)a.qkv, (float*)a.att, a.stat, nseq, L, heads, causal, s));
     else CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
-    CK(linear(f32, a.att, P[4], a.x1, (int)T, D, D, P[5], xin, nullptr, 0, workspace, ws_bytes, s));
-    CK(hmmc_layernorm_fwd(a.x1, (const float*)P[6], (const float*)P[7], a.ln2, a.m2, a.r2, nullptr, (int)T, D, D, eps, dt, s));
-    // fp16 tower: the `h` slot receives QuickGELU'(pre-activation), which is all the backward needs of it
-    CK(linear(f32, a.ln2, P[8], a.g, (int)T, 4 * D, D, P[9], nullptr, keep_acts ? a.h : nullptr,
-              EPI_QGELU | ((!f32 && keep_acts) ? EPI_SAVE_DGELU : 0), workspace, ws_bytes, s));
     // output of this layer: next layer's saved input slot, or y for the last layer.  Without saved activations one
     // slab is reused: the output alternates between the x and h slots (h is dead once c_proj has read g, and the
     // next layer's input is dead before its own c_fc rewrites h).
     void* out = y;
     if (i + 1 < nlayers) out = keep_acts ? carve((char*)acts + (size_t)(i + 1) * slab, T, D, nseq, L, heads, es, f32).x
                                          : (void*)(((i & 1) == 0) ? a.x : a.h);
+    const int save_epi = EPI_QGELU | ((!f32 && keep_acts) ? EPI_SAVE_DGELU : 0);
+    if (lead_only && i + 1 == nlayers) {
+      // leading rows only: x1 and y are addressed in place (row n*L of the [T, D] buffers), ln2 / g / h are compact [nseq, .]
+      const int ldl = L * D;
+      CK(hmmc_gemm_f16(a.att, P[4], a.x1, nseq, D, D, ldl, D, ldl, 1, 1, P[5], xin, nullptr, nullptr, EPI_BIAS | EPI_RESID,
+                       nullptr, 0, s));
+      CK(hmmc_layernorm_fwd(a.x1, (const float*)P[6], (const float*)P[7], a.ln2, a.m2, a.r2, nullptr, nseq, D, ldl, eps, dt, s));
+      CK(linear(f32, a.ln2, P[8], a.g, nseq, 4 * D, D, P[9], nullptr, keep_acts ? a.h : nullptr, save_epi, workspace, ws_bytes, s));
+      CK(hmmc_gemm_f16(a.g, P[10], out, nseq, D, 4 * D, 4 * D, 4 * D, ldl, 1, 1, P[11], a.x1, nullptr, nullptr,
+                       EPI_BIAS | EPI_RESID, nullptr, 0, s));
+      cur = out;
+      continue;
+    }
+    CK(linear(f32, a.att, P[4], a.x1, (int)T, D, D, P[5], xin, nullptr, 0, workspace, ws_bytes, s));
+    CK(hmmc_layernorm_fwd(a.x1, (const float*)P[6], (const float*)P[7], a.ln2, a.m2, a.r2, nullptr, (int)T, D, D, eps, dt, s));
+    // fp16 tower: the `h` slot receives QuickGELU'(pre-activation), which is all the backward needs of it
+    CK(linear(f32, a.ln2, P[8], a.g, (int)T, 4 * D, D, P[9], nullptr, keep_acts ? a.h : nullptr, save_epi, workspace, ws_bytes, s));
     CK(linear(f32, a.g, P[10], out, (int)T, D, 4 * D, P[11], a.x1, nullptr, 0, workspace, ws_bytes, s));
     cur = out;
   }
@@ -209,9 +228,10 @@ struct WgradSync {
 // gradients (stream order), so the caller sees ordinary single-stream semantics.
 extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads,
                               const void* acts, void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal,
-                              int fp32, void* workspace, size_t ws_bytes, hipStream_t wgrad_stream, hipStream_t s) {
+                              int fp32, int lead_only, void* workspace, size_t ws_bytes, hipStream_t wgrad_stream, hipStream_t s) {
   if (!dy || !dx || !x0 || !params || !grads || !acts || !scratch || nseq <= 0 || L <= 0 || nlayers <= 0 || D != heads * 64)
     return HMMC_ERR_ARG;
+  if (lead_only && fp32) return HMMC_ERR_UNSUPPORTED;
   const bool f32 = fp32 != 0;
   const int es = f32 ? 4 : 2, dt = f32 ? 1 : 0;
   const long T = (long)nseq * L;
@@ -238,11 +258,12 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
   WgradSync sync(two);
   if (two && !sync.ok) return HMMC_ERR_LAUNCH;
   // weight gradient k of a layer (0: c_proj <- g_in, 1: c_fc <- dh, 2: out_proj <- dx1, 3: in_proj <- dqkv)
-  auto side_wgrad = [&](int k, const void* dyk, const void* xk, void* dW, int Np, int Kp) -> int {
+  auto side_wgrad = [&](int k, const void* dyk, const void* xk, void* dW, int Np, int Kp, int rows = 0, int ldy = 0,
+                        int ldx = 0) -> int {
     if (two) {
       if (hipEventRecord(sync.ready, s) != hipSuccess || hipStreamWaitEvent(sw, sync.ready, 0) != hipSuccess) return HMMC_ERR_LAUNCH;
     }
-    int rc = wgrad(f32, dyk, xk, dW, (int)T, Np, Kp, two ? wws : workspace, two ? wws_bytes : gen, sw);
+    int rc = wgrad(f32, dyk, xk, dW, rows ? rows : (int)T, Np, Kp, two ? wws : workspace, two ? wws_bytes : gen, sw, ldy, ldx);
     if (rc == 0 && two) {
       if (hipEventRecord(sync.done[k], sw) != hipSuccess) return HMMC_ERR_LAUNCH;
       sync.done_set[k] = true;
@@ -255,13 +276,33 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
     return 0;
   };
   const void* g_in = dy;
-  CK(hmmc_colsum(dy, grads[(size_t)(nlayers - 1) * 12 + 11], (int)T, D, D, dt, dt, 0, workspace, gen, s));
+  const int ldl = L * D;                         // lead_only: row stride between the leading tokens of consecutive sequences
+  if (lead_only) CK(hmmc_colsum(dy, grads[(size_t)(nlayers - 1) * 12 + 11], nseq, D, ldl, dt, dt, 0, workspace, gen, s));
+  else CK(hmmc_colsum(dy, grads[(size_t)(nlayers - 1) * 12 + 11], (int)T, D, D, dt, dt, 0, workspace, gen, s));
   for (int i = nlayers - 1; i >= 0; --i) {
     const void* const* P = params + (size_t)i * 12;
     void* const* G = grads + (size_t)i * 12;
     Acts a = carve((char*)acts + (size_t)i * slab, T, D, nseq, L, heads, es, f32);
     const void* xin = i == 0 ? x0 : (const void*)a.x;
     void* g_out = i == 0 ? dx : ping[i & 1];
+    if (lead_only && i + 1 == nlayers) {
+      // Last block, leading rows only (see hmmc_tower_fwd): g_in = dy and x1 / att are addressed at stride L*D, dh / dln / ln2 /
+      // g / h are compact [nseq, .].  dx1 and the attention-output gradient are full [T, D] buffers that the attention and
+      // ln_1 backward read whole: zero everywhere except the leading rows.
+      if (hipMemsetAsync(dx1, 0, (size_t)T * D * es, s) != hipSuccess) return HMMC_ERR_LAUNCH;
+      CK(side_wgrad(0, g_in, a.g, G[10], D, 4 * D, nseq, ldl, 0));
+      const int rows = (int)hmmc_gemm_f16_colsum_rows(nseq, 4 * D, D);
+      CK(hmmc_gemm_f16(g_in, P[10], dh, nseq, 4 * D, D, ldl, 4 * D, 4 * D, 1, 0, nullptr, nullptr, nullptr, a.h,
+                       EPI_MULAUX | EPI_COLSUM, part, part_bytes, s));
+      CK(hmmc_colsum(part, G[9], rows, 4 * D, 4 * D, 1, dt, 0, workspace, gen, s));
+      CK(side_wgrad(1, dh, a.ln2, G[8], 4 * D, D, nseq));
+      CK(dgrad(f32, dh, P[8], dln, nseq, 4 * D, D, nullptr, 0, s));
+      CK(hmmc_layernorm_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], G[5], nullptr,
+                            nseq, D, ldl, dt, workspace, gen, s));             // G[5]: out_proj bias = colsum(dx1 rows)
+      CK(side_wgrad(2, dx1, a.att, G[4], D, D, nseq, ldl, ldl));
+      if (hipMemsetAsync(dln, 0, (size_t)T * D * es, s) != hipSuccess) return HMMC_ERR_LAUNCH;
+      CK(hmmc_gemm_f16(dx1, P[4], dln, nseq, D, D, ldl, D, ldl, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, s));
+    } else {
     // MLP: x2 = x1 + c_proj(QuickGELU(c_fc(ln2)))
     CK(side_wgrad(0, g_in, a.g, G[10], D, 4 * D));
     CK(before_overwrite(1));
@@ -281,6 +322,7 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
     // attention: x1 = x + out_proj(attn(in_proj(ln1)))
     CK(side_wgrad(2, dx1, a.att, G[4], D, D));
     CK(dgrad(f32, dx1, P[4], dln, (int)T, D, D, nullptr, 0, s));                 // datt (reuses dln)
+    }
     CK(before_overwrite(3));
     if (f32) {
       CK(hmmc_temporal_attention_bwd((const float*)a.qkv, a.stat, (const float*)dln, (float*)dqkv, nseq, L, heads, s));

@@ -90,8 +90,9 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep):
-    """Run all layers through the native layer runtime (hmmc_tower_fwd).  Returns (y, acts slab or None)."""
+def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep, lead_only=False):
+    """Run all layers through the native layer runtime (hmmc_tower_fwd).  Returns (y, acts slab or None).
+    lead_only: only token 0 of every sequence of y is defined (see include/hmmc_hip.h)."""
     from ._lib import call, ptr, query
     T, D = x.shape
     nl = len(params) // PER_LAYER
@@ -101,14 +102,14 @@ def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep):
     ws = ops.workspace(wsb, x.device, "tower")
     y = torch.empty_like(x)
     call("hmmc_tower_fwd", ptr(x), ptr(y), _ptr_array(params), ptr(acts), int(keep), nseq, L, heads, D, nl, int(causal),
-         float(eps), int(fp32), ptr(ws), wsb)
+         float(eps), int(fp32), int(lead_only), ptr(ws), wsb)
     return y, (acts if keep else None)
 
 
 _WGRAD_STREAM = os.environ.get("HMMC_WGRAD_STREAM", "1") != "0"
 
 
-def _tower_backward(dy, x0, params, acts, nseq, L, heads, causal, fp32):
+def _tower_backward(dy, x0, params, acts, nseq, L, heads, causal, fp32, lead_only=False):
     from ._lib import call, ptr, query
     T, D = x0.shape
     nl = len(params) // PER_LAYER
@@ -120,7 +121,7 @@ def _tower_backward(dy, x0, params, acts, nseq, L, heads, causal, fp32):
     # weight gradients on their own stream (leaves of the backward): the library orders the two streams itself
     wst = ops.aux_stream(x0.device, "wgrad").cuda_stream if _WGRAD_STREAM else None
     call("hmmc_tower_bwd", ptr(dy), ptr(dx), ptr(x0), _ptr_array(params), _ptr_array(grads), ptr(acts), ptr(scratch), nseq, L,
-         heads, D, nl, int(causal), int(fp32), ptr(ws), wsb, wst)
+         heads, D, nl, int(causal), int(fp32), int(lead_only), ptr(ws), wsb, wst)
     return dx, grads
 
 
@@ -129,23 +130,23 @@ class ClipTransformerFn(torch.autograd.Function):
     LayerNorm statistics); the per-layer activations live in a single slab laid out by the library."""
 
     @staticmethod
-    def forward(ctx, x, nseq, L, heads, causal, *params):
+    def forward(ctx, x, nseq, L, heads, causal, lead_only, *params):
         keep = any(ctx.needs_input_grad)       # momentum (key) encoders and eval run under no_grad
         x = x.contiguous()
         for prm in params:
             if not prm.is_contiguous():
                 raise ValueError("tower parameters must be contiguous")
-        y, acts = _tower_forward(x, params, nseq, L, heads, causal, 1e-5, False, keep)
+        y, acts = _tower_forward(x, params, nseq, L, heads, causal, 1e-5, False, keep, lead_only)
         ctx.acts, ctx.x0, ctx.params = acts, (x if keep else None), params
-        ctx.cfg = (nseq, L, heads, causal)
+        ctx.cfg = (nseq, L, heads, causal, lead_only)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        nseq, L, heads, causal = ctx.cfg
-        dx, grads = _tower_backward(dy.contiguous(), ctx.x0, ctx.params, ctx.acts, nseq, L, heads, causal, False)
+        nseq, L, heads, causal, lead_only = ctx.cfg
+        dx, grads = _tower_backward(dy.contiguous(), ctx.x0, ctx.params, ctx.acts, nseq, L, heads, causal, False, lead_only)
         ctx.acts = ctx.x0 = None
-        return (dx, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, *grads)
 
 
 class LnProjFn(torch.autograd.Function):

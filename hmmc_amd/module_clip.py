@@ -68,8 +68,9 @@ class Transformer(nn.Module):
             out += Fn.block_params(blk)
         return out
 
-    def forward(self, x, nseq, L):
-        """x: [nseq*L, width] fp16 -> same shape."""
+    def forward(self, x, nseq, L, lead_only=False):
+        """x: [nseq*L, width] fp16 -> same shape.  lead_only: the caller reads only token 0 of every sequence of the result
+        (the class token), so the last block's per-token half runs on those rows alone; the other rows are undefined."""
         if x.dtype != torch.float16:
             raise NotImplementedError("the HIP CLIP towers run the reference's as-written fp16 regime; "
                                       "model.float() (fp32-upcast) is not supported on this path")
@@ -86,7 +87,7 @@ class Transformer(nn.Module):
             params = []
             for blk in blocks[i:i + per]:
                 params += Fn.block_params(blk)
-            x = Fn.ClipTransformerFn.apply(x, nseq, L, self.heads, self.causal, *params)
+            x = Fn.ClipTransformerFn.apply(x, nseq, L, self.heads, self.causal, bool(lead_only and i + per >= self.layers), *params)
         return x
 
 
@@ -117,13 +118,13 @@ class VisualTransformer(nn.Module):
         h = self.hidden_tokens(x)
         return h.view(n, self.tokens, -1)
 
-    def hidden_tokens(self, x):
+    def hidden_tokens(self, x, lead_only=False):
         n = x.shape[0]
         # the kernel casts fp32 pixels to fp16 while patchifying (image.type(fp16)); raw uint8 frames are normalised there too
         x = x.contiguous() if x.dtype == torch.uint8 else x.float().contiguous()
         t = Fn.VitEmbedFn.apply(x, self.conv1.weight, self.class_embedding, self.positional_embedding,
                                 self.ln_pre.weight, self.ln_pre.bias)
-        return self.transformer(t, n, self.tokens)
+        return self.transformer(t, n, self.tokens, lead_only)
 
 
 def convert_weights(model: nn.Module):

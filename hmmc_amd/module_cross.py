@@ -136,7 +136,8 @@ class VisualEncoder(nn.Module):
         rows are normalised and projected unless return_hidden asks for all tokens."""
         n = image.shape[0]
         L = self.visual.tokens
-        tokens = self.visual.hidden_tokens(image)
+        # without return_hidden only the class-token row of the last block is consumed: its per-token half runs on that row alone
+        tokens = self.visual.hidden_tokens(image, lead_only=not return_hidden)
         v = self.visual
         if return_hidden:
             hidden = Fn.LnProjFn.apply(tokens, None, v.ln_post.weight, v.ln_post.bias, v.proj).view(n, L, -1)

@@ -222,14 +222,20 @@ int hmmc_ce_bwd(float* logits, const long* labels, const float* lse, const float
 size_t hmmc_tower_act_bytes(long tokens, int D, int nseq, int L, int heads, int fp32);
 size_t hmmc_tower_bwd_scratch_bytes(long tokens, int D, int fp32);
 size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32);
+/* lead_only (fp16 towers, 0 / 1): the caller consumes only token 0 of every sequence of y - the ViT class token, the only
+ * row VisualEncoder.encode_image keeps (modules/module_cross.py:228-230).  The last block's out_proj, ln_2 and MLP are
+ * per-token, so they then run on the nseq leading rows alone (addressed in place at stride L*D); the other rows of y are
+ * undefined, and hmmc_tower_bwd with the same flag reads only the leading rows of dy.  Loss and gradients are unchanged:
+ * no gradient reaches the rows that are skipped. */
 int hmmc_tower_fwd(const void* x, void* y, const void* const* params, void* acts, int keep_acts, int nseq, int L, int heads,
-                   int D, int nlayers, int causal, float eps, int fp32, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+                   int D, int nlayers, int causal, float eps, int fp32, int lead_only, void* workspace, size_t ws_bytes,
+                   hmmc_stream_t stream);
 /* wgrad_stream (optional, NULL = `stream`): a second stream for the weight-gradient GEMMs, which are leaves of the backward
  * pass; they then run beside the dgrad / LayerNorm / attention chain.  `stream` waits for it before the call's work is
  * complete in stream order, so callers keep single-stream semantics. */
 int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads, const void* acts,
-                   void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal, int fp32, void* workspace,
-                   size_t ws_bytes, hmmc_stream_t wgrad_stream, hmmc_stream_t stream);
+                   void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal, int fp32, int lead_only,
+                   void* workspace, size_t ws_bytes, hmmc_stream_t wgrad_stream, hmmc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,10 @@ def close(a, b, atol, rtol=0.0, what=""):
 
 # ----------------------------------------------------------------------------- fp32 kernels
 
+def relerr(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
 def test_gemm_f32_all_orientations():
     g = torch.Generator().manual_seed(0)
     for (M, N, K) in [(64, 64, 16), (100, 36, 52), (50, 40, 203), (384, 512, 2048), (256, 3328, 512), (3328, 512, 256)]:
@@ -115,6 +119,39 @@ def test_eval_scorer_ranks_identical():
             assert np.array_equal(M.ranks(sv + fk), m["ranks"])
             mo = O.compute_metrics((sv + fk).cpu().numpy().T)
             assert np.array_equal(M.ranks(sv + fk, transposed=True), mo["ranks"]) and mvt["R1"] == mo["R1"]
+
+
+@pytest.mark.parametrize("width,heads,L,nseq,layers", [(128, 2, 10, 37, 3), (768, 12, 50, 96, 2)])
+def test_tower_lead_only_equals_full_tower(width, heads, L, nseq, layers):
+    """hmmc_tower_fwd/bwd with lead_only run the last block's per-token half on the class-token rows alone: those rows of
+    the output, the input gradient and every parameter gradient must equal the full computation's (no gradient reaches the
+    skipped rows; weight gradients differ only in the order of their fp32 partial sums)."""
+    from hmmc_amd import module_clip
+    torch.manual_seed(3)
+    tw = module_clip.Transformer(width, layers, heads)
+    for prm in tw.parameters():
+        torch.nn.init.normal_(prm, std=0.05 if prm.dim() > 1 else 0.1)
+    for blk in tw.resblocks:
+        blk.ln_1.weight.data.add_(1.0)
+        blk.ln_2.weight.data.add_(1.0)
+    module_clip.convert_weights(tw)
+    tw = tw.to(DEV)
+    x0 = (torch.randn(nseq * L, width) * 0.5).half().to(DEV)
+    wsel = torch.randn(nseq, width).to(DEV)
+    res = []
+    for lead in (False, True):
+        for prm in tw.parameters():
+            prm.grad = None
+        x = x0.clone().requires_grad_()
+        y = tw(x, nseq, L, lead_only=lead)
+        cls = y.view(nseq, L, width)[:, 0, :]
+        (cls.float() * wsel).sum().backward()
+        res.append((cls.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in tw.named_parameters()}))
+    (c0, dx0, g0), (c1, dx1, g1) = res
+    assert torch.equal(c0, c1), f"class-token rows differ: {(c0.float() - c1.float()).abs().max()}"
+    assert relerr(dx1, dx0) < 1e-3, relerr(dx1, dx0)
+    for n in g0:
+        assert relerr(g1[n], g0[n]) < 2e-3, (n, relerr(g1[n], g0[n]))
 
 
 def test_temporal_fn_vs_oracle():
