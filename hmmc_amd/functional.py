@@ -271,7 +271,7 @@ class MlpFn(torch.autograd.Function):
         x = x.contiguous()
         h = ops.linear_f32(x, w1, bias=b1)
         sums = ops.bn_stats(h)
-        n_local = torch.tensor([float(h.shape[0])], device=h.device)
+        n_local = torch.full((1,), float(h.shape[0]), device=h.device)      # a fill kernel: torch.tensor(..., device=) is a blocking copy
         packed = _sync_sum(torch.cat([sums.view(-1), n_local]))
         n = packed[-1]
         mean = packed[:h.shape[1]] / n
@@ -295,7 +295,8 @@ class MlpFn(torch.autograd.Function):
         # dx needs the sums over every rank's rows
         dbeta, dgamma = local[0].clone(), local[1].clone()
         sums = _sync_sum(local.clone()) if _world() > 1 else local
-        dh = ops.bn_bwd_apply(dy, y, h, mean, rstd, gamma, sums, n_global=float(n))
+        # sums / n on the device (n is the all-reduced row count): reading n on the host would stall the launch stream
+        dh = ops.bn_bwd_apply(dy, y, h, mean, rstd, gamma, (sums / n).contiguous(), n_global=1.0)
         dw1 = ops.wgrad_f32(dh, x)
         db1 = ops.colsum(dh)
         dx = ops.dgrad_f32(dh, w1)

@@ -148,6 +148,10 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
             q = torch.randn(E, width)
             self.register_buffer(name, torch.nn.functional.normalize(q, dim=0))
         self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        # host copy of queue_ptr: the reference reads the device buffer with int() every step (modeling.py:270), which stalls
+        # the launch stream; the buffer stays the source of truth and is re-read once after construction / load_state_dict
+        self._queue_ptr_host = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: setattr(module, "_queue_ptr_host", None))
         self.loss_fct = CrossEn()
         self._ema_table = None
         self._mlm_draws = None          # tests inject the reference's recorded random draws here
@@ -188,13 +192,14 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
         v, tag, title = packed[:, :E], packed[:, E:2 * E], packed[:, 2 * E:3 * E]
         fr = packed[:, 3 * E:3 * E + F * E].reshape(B * F, E)
         fp = packed[:, 3 * E + F * E:].reshape(B * F, E)
-        ptr_ = int(self.queue_ptr)
+        ptr_ = self._queue_ptr_host if self._queue_ptr_host is not None else int(self.queue_ptr)
         ops.enqueue(v.contiguous(), self.queue_v_cross_ng, ptr_)
         ops.enqueue(tag.contiguous(), self.queue_tag_cross_ng, ptr_)
         ops.enqueue(title.contiguous(), self.queue_title_cross_ng, ptr_)
         ops.enqueue(fp.contiguous(), self.queue_frame_proj_ng, ptr_ * F)
         ops.enqueue(fr.contiguous(), self.queue_frame_cross_ng, ptr_ * F)
-        self.queue_ptr[0] = (ptr_ + B) % self.contrast_num_negative
+        self._queue_ptr_host = (ptr_ + B) % self.contrast_num_negative
+        self.queue_ptr.fill_(self._queue_ptr_host)
 
     # ---- MLP with train-mode BatchNorm (batch statistics shared over ranks)
     def _mlp(self, mlp, x):

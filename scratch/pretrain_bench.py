@@ -25,5 +25,13 @@ for i in range(2): step(i)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 5
 for i in range(n): loss = step(2 + i)
+t_issue = (time.perf_counter() - t0) / n          # host time to enqueue a step (includes the MLM row-list read)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"pre-train step B={B} F={F} K={K}: {dt*1e3:.1f} ms/step, {B/dt:.0f} pairs/s, loss {float(loss):.4f}, losses {[round(float(x), 3) for x in model.last_losses]}, mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+print(f"pre-train step B={B} F={F} K={K}: host enqueue {t_issue*1e3:.1f} ms/step; {dt*1e3:.1f} ms/step, {B/dt:.0f} pairs/s, loss {float(loss):.4f}, losses {[round(float(x), 3) for x in model.last_losses]}, mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+import os
+if os.environ.get("PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for i in range(5): step(10 + i)
+    pr.disable(); torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("cumtime").print_stats(45)

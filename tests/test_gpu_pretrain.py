@@ -137,6 +137,17 @@ def test_pretrain_steps_vs_reference_golden():
                 q = S[qn][:32].float().cpu().numpy()
                 assert np.isfinite(q).all()
                 close(np.linalg.norm(S[qn].float().cpu().numpy(), axis=0), 1.0, 1e-4, what=f"{qn} column norms")
+    # the model keeps a host copy of queue_ptr (no device read per step); a checkpoint load must invalidate it
+    S = {k: v.clone() for k, v in model.state_dict().items()}
+    S["queue_ptr"] = torch.tensor([2 * B], dtype=torch.long)
+    model.load_state_dict(S)
+    vid, vf, tg, gm, ti, tm = [t.to(DEV) for t in synth.pretrain_batch(B, Fr, tag="moco.s0")]
+    model._mlm_draws = None
+    before = model.queue_v_cross_ng.clone()
+    model(vid, vf, tg, gm, ti, tm, 6)
+    assert int(model.queue_ptr) == (3 * B) % K
+    changed = (model.queue_v_cross_ng != before).any(dim=0).nonzero().view(-1).tolist()
+    assert changed == list(range(2 * B, 3 * B)), changed
 
 
 def test_pretrain_gradients_vs_oracle():
