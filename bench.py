@@ -166,7 +166,7 @@ def main():
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_dev], output_device=local_dev,
-                                                        find_unused_parameters=False, gradient_as_bucket_view=False)
+                                                        find_unused_parameters=False, gradient_as_bucket_view=True)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     res = synth.NAMED[args.clip].image_res
     video = torch.randn((b, args.frames, 3, res, res), generator=g, device=dev)

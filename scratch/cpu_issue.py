@@ -7,6 +7,14 @@ from hmmc_amd import synth
 from hmmc_amd.modeling import BirdModel
 from hmmc_amd.optimization import clip_grad_norm_
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+if os.environ.get("RESERVE"):
+    from hmmc_amd import ops as _o
+    os.environ["HMMC_RCCL_CUS"] = os.environ["RESERVE"]; _o.reserve_cus_for_collectives()
+if os.environ.get("PG"):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 cfg = bench.task_config(local_rank=0, rank=0, max_frames=12, pretrained_clip_name="ViT-B/32")
 torch.manual_seed(42)
 model = BirdModel.from_pretrained("cross-base", state_dict=None, task_config=cfg).cuda().train()
