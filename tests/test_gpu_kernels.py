@@ -79,6 +79,28 @@ def test_gemm_big_tile_exact_integers(layout, M, N, K):
     assert torch.equal(c.float(), ref), f"max diff {(c.float()-ref).abs().max()}"
 
 
+@pytest.mark.parametrize("nseq,L,N,K", [(96, 50, 768, 768), (37, 10, 128, 512)])
+def test_gemm_strided_rows(nseq, L, N, K):
+    """Row strides larger than the row length on A, C and the residual (the class-token rows of a [tokens, D] buffer,
+    hmmc_tower_fwd's lead_only path): only the addressed rows are read and written."""
+    from hmmc_amd._lib import call, ptr
+    full_a = ints(nseq * L, K, lo=-1, hi=2)
+    w, bias = ints(N, K, lo=-1, hi=2, seed=1), ints(N, lo=-2, hi=3, seed=2)
+    full_r = ints(nseq * L, N, lo=-2, hi=3, seed=3)
+    out = torch.full((nseq * L, N), 7.0, dtype=torch.float16, device=DEV)
+    call("hmmc_gemm_f16", ptr(full_a), ptr(w), ptr(out), nseq, N, K, L * K, K, L * N, 1, 1, ptr(bias), ptr(full_r), None, None,
+         ops.EPI_BIAS | ops.EPI_RESID, None, 0)
+    a_rows, r_rows = full_a.view(nseq, L, K)[:, 0], full_r.view(nseq, L, N)[:, 0]
+    ref = a_rows.float() @ w.float().t() + bias.float() + r_rows.float()
+    o3 = out.view(nseq, L, N)
+    assert torch.equal(o3[:, 0].float(), ref)
+    assert bool((o3[:, 1:] == 7.0).all()), "rows between the addressed ones were written"
+    # weight-gradient layout with strided operands: dW[N, K] = sum over the addressed rows of dy^T x
+    dw = torch.empty(N, K, dtype=torch.float16, device=DEV)
+    call("hmmc_gemm_f16", ptr(full_r), ptr(full_a), ptr(dw), N, K, nseq, L * N, L * K, K, 0, 0, None, None, None, None, 0, None, 0)
+    assert torch.equal(dw.float(), r_rows.float().t() @ a_rows.float())
+
+
 def test_gemm_with_reserved_cus():
     """hmmc_gemm_reserve_cus only shrinks the persistent grid: results are unchanged, bad counts are refused."""
     from hmmc_amd import _lib
@@ -328,3 +350,10 @@ def test_error_statuses_instead_of_faults():
              128, 768, 768, 0, ptr(small), 16)
     with pytest.raises(TypeError):
         ops.gemm_f16(a.cpu(), w, 64, 64, 72)                        # host tensors are rejected: there is no CPU path
+    # lead_only is an fp16-tower mode
+    from hmmc_amd import functional as Fn
+    xf = torch.randn(4 * 6, 64, device=DEV)
+    prm = [torch.randn(s, device=DEV) for s in ((64,), (64,), (192, 64), (192,), (64, 64), (64,), (64,), (64,), (256, 64), (256,),
+                                                 (64, 256), (64,))]
+    with pytest.raises(RuntimeError, match="unsupported"):
+        Fn._tower_forward(xf, prm, 4, 6, 1, False, 1e-12, True, False, lead_only=True)
