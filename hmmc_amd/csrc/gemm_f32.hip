@@ -237,27 +237,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
   // A wave issues in order, so whatever sits between the last MFMA of one step and the first of the next is exposed: the
   // LDS reads, the staging stores (which wait for the global data) and the refill are therefore placed between the four
   // 4-MFMA groups of the step, where they issue in the shadow of the 32-cycle MFMAs.
-  auto mfma4 = [&](const Frags& f, int kk) {
+  auto mfma2 = [&](const Frags& f, int kk, int i) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[kk][j], f.a[kk][i], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[kk][j], f.a[kk][i], acc[i][j], 0, 0, 0);
   };
+  auto read_part = [&](int buf, Frags& f, int kk) {
+    const float* a = sA[buf];
+    const float* b = sB[buf];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f.a[kk][i] = a[(4 * kk + (lane >> 4)) * LDS_LD + wm * 32 + i * 16 + (lane & 15)];
+      f.b[kk][i] = b[(4 * kk + (lane >> 4)) * LDS_LD + wn * 32 + i * 16 + (lane & 15)];
+    }
+  };
+#define HMMC_PIN() __builtin_amdgcn_sched_barrier(0)
   auto step = [&](int kt, const Frags& cur, Frags& nxt, f4& sa, f4& sb) {
-    mfma4(cur, 0);
-    read_frags((kt + 1) & 1, nxt);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma4(cur, 1);
-    store_op<AMODE>(sA[kt & 1], sa, p.sak, p.K, (kt + 2) * TK, tid);
-    store_op<BMODE>(sB[kt & 1], sb, p.sbk, p.K, (kt + 2) * TK, tid);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma4(cur, 2);
+    // eight pairs of MFMAs (64 cycles of the matrix pipe each); between them, in order: the four fragment-read pairs of step
+    // kt + 1, the two staging stores of step kt + 2, the two refills
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      mfma2(cur, kk, 0); read_part((kt + 1) & 1, nxt, 2 * kk); HMMC_PIN();
+      mfma2(cur, kk, 1); read_part((kt + 1) & 1, nxt, 2 * kk + 1); HMMC_PIN();
+    }
+    mfma2(cur, 2, 0); store_op<AMODE>(sA[kt & 1], sa, p.sak, p.K, (kt + 2) * TK, tid); HMMC_PIN();
+    mfma2(cur, 2, 1); store_op<BMODE>(sB[kt & 1], sb, p.sbk, p.K, (kt + 2) * TK, tid); HMMC_PIN();
+    mfma2(cur, 3, 0);
     sa = fetch_op<AMODE>(p.A, p.sam, p.sak, p.M, p.K, m0, (kt + 2 + PD) * TK, tid);
     sb = fetch_op<BMODE>(p.B, p.sbn, p.sbk, p.N, p.K, n0, (kt + 2 + PD) * TK, tid);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma4(cur, 3);
+    HMMC_PIN();
+    mfma2(cur, 3, 1);
     __syncthreads();
   };
+#undef HMMC_PIN
   for (int kt = 0; kt < nkt; kt += PD) {          // slots and buffers rotate with period PD (even): static register indices
 #pragma unroll
     for (int s = 0; s < PD; s += 2) {
