@@ -339,6 +339,26 @@ def test_train_steps_vs_reference_golden():
             assert np.mean(cos) > 0.6, f"step {step}: weight movement disagrees with the reference: {cos}"
 
 
+def test_encode_image_all_tokens_and_class_token_paths_agree():
+    """encode_image(return_hidden=True) runs the full last block and returns every token's projection (the reference's
+    `hidden`, module_cross.py:228-236); the default path prunes the last block to the class token.  Both give the same
+    class-token feature, bit for bit, and module_clip.VisualTransformer.forward() still returns all tokens."""
+    model, _ = build(synth.TINY)
+    model.eval()
+    _, _, vid, _, _ = synth.finetune_batch(3, 4, 32, tag="hid")
+    frames = vid.view(-1, *vid.shape[2:]).to(DEV)
+    enc = model.visual_encoder
+    with torch.no_grad():
+        feat = enc.encode_image(frames)
+        feat_h, hidden = enc.encode_image(frames, return_hidden=True)
+        tokens = enc.visual(frames)
+    L = enc.visual.tokens
+    assert hidden.shape == (frames.shape[0], L, feat.shape[-1]) and tokens.shape[:2] == (frames.shape[0], L)
+    assert torch.equal(feat, feat_h) and torch.equal(feat_h, hidden[:, 0, :])
+    assert bool(torch.isfinite(hidden).all()) and bool(torch.isfinite(tokens.float()).all())
+    assert float(hidden[:, 1:].float().abs().mean()) > 0          # the other tokens are computed, not left undefined
+
+
 def test_uint8_frames_equal_normalised_fp32_frames():
     """raw uint8 frames with the loader's normalisation fused into the patch extraction give the
     same loss and gradients as the fp32 frames the reference's loader hands over."""
