@@ -216,8 +216,10 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
   auto store2 = [&](half_t* dst, int i, u4 o0, u4 o1) {
     char* sb = reinterpret_cast<char*>(dst) + ((size_t)(m_base + 16 * i) * p.ldc + n0) * 2u;
     if (FULL) {
-      *reinterpret_cast<u4*>(sb + voff) = o0;
-      *reinterpret_cast<u4*>(sb + row8 + voff) = o1;
+      // streaming stores: a tile's output is next read by another kernel, long after the operand panels that the K loops
+      // keep re-reading from L2 have passed (per layer 6 877-7 019 -> 6 770 us in scratch/gemm_bench.py, step -0.5 %)
+      __builtin_nontemporal_store(o0, reinterpret_cast<u4*>(sb + voff));
+      __builtin_nontemporal_store(o1, reinterpret_cast<u4*>(sb + row8 + voff));
     } else {
       const int m0 = m_base + 16 * i + r_l;
       if (m0 < p.M && n_ok) *reinterpret_cast<u4*>(sb + voff) = o0;
