@@ -474,6 +474,17 @@ extern "C" int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int 
   if (!X || !out || M <= 0 || N <= 0) return HMMC_ERR_ARG;
   int vn = in_dtype == 0 ? 8 : 4;
   if (N % vn || ld % vn) return HMMC_ERR_UNSUPPORTED;
+  // a few hundred dense fp32 rows (the partial sums a producer kernel left behind, at small batches): the second stage alone
+  // reads them directly - one launch instead of two on the critical path of the backward pass
+  if (in_dtype != 0 && ld == N && M <= 512) {
+    if (out_dtype == 0)
+      hipLaunchKernelGGL(colreduce_kernel<half_t>, dim3((N + 31) / 32), dim3(256), 0, stream, (const float*)X, (half_t*)out,
+                         (half_t*)out, M, N, N, round_f16);
+    else
+      hipLaunchKernelGGL(colreduce_kernel<float>, dim3((N + 31) / 32), dim3(256), 0, stream, (const float*)X, (float*)out,
+                         (float*)out, M, N, N, round_f16);
+    return hmmc_launch_status();
+  }
   int rb = colsum_slabs(M);
   int rpb = (M + rb - 1) / rb;
   rb = (M + rpb - 1) / rpb;
