@@ -85,8 +85,49 @@ __device__ __forceinline__ void store_t(half_t* dst, long ld, int row0, int L, c
     }
 }
 
-// one wave per (sequence, head, 64-query block)
-__global__ __launch_bounds__(256) void attn_long_fwd_kernel(AttnArgs p) {
+// ---- register-fragment helpers (the layout of attention_f16.hip: operand rows straight from global memory into MFMA
+// fragments, one 9 KiB LDS tile per wave for the transposed operand) -----------------------------------------------------
+__device__ __forceinline__ h8 gfrag_clamped(const half_t* src, int row0, int ks, int L, long ld, int lane) {
+  int row = min(row0 + (lane & 15), L - 1);
+  return *reinterpret_cast<const h8*>(src + (long)row * ld + ks * 32 + 8 * (lane >> 4));
+}
+__device__ __forceinline__ void frags_to_tile(half_t* tile, const h8 (&f)[4][2], int lane) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      *reinterpret_cast<h8*>(tile + (t * 16 + (lane & 15)) * LDS_STRIDE + ks * 32 + 8 * (lane >> 4)) = f[t][ks];
+}
+// X^T accumulators of one 16-row tile (4 d-tiles) -> global row `row`, 16 B per lane (v_permlane16_swap pairs the d-tiles)
+__device__ __forceinline__ void store_row16(half_t* dst, long ld, const f4 (&acc)[4], int row, bool ok, int lane) {
+  const int g = lane >> 4;
+  unsigned d[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    h4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (half_t)acc[dt][r];
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    u2v u = __builtin_bit_cast(u2v, v);
+    d[dt][0] = u[0]; d[dt][1] = u[1];
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      auto r = __builtin_amdgcn_permlane16_swap(d[2 * q][e], d[2 * q + 1][e], false, false);
+      d[2 * q][e] = r[0]; d[2 * q + 1][e] = r[1];
+    }
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    u4v o = {d[2 * q][0], d[2 * q][1], d[2 * q + 1][0], d[2 * q + 1][1]};
+    if (ok) *reinterpret_cast<u4v*>(dst + (long)row * ld + 32 * q + 16 * (g & 1) + 8 * (g >> 1)) = o;
+  }
+}
+
+// Forward: one wave per (sequence, head, 64-query block), online softmax over 64-key blocks.  Q, K and V rows go from
+// global memory straight into MFMA fragments; only V passes through the wave's LDS tile (transposed reads for O^T = V^T P^T),
+// so a workgroup of four waves needs 36 KiB and two waves per SIMD stay resident.
+__global__ __launch_bounds__(256, 2) void attn_long_fwd_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -101,13 +142,16 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(AttnArgs p) {
   const half_t* q = p.qkv + (long)n * L * ld + h * DH;
   const half_t* k = q + D;
   const half_t* v = q + 2 * D;
-  half_t* base = reinterpret_cast<half_t*>(smem) + wid * (3 * TILE);
-  half_t* qtile = base; half_t* ktile = base + TILE; half_t* vtile = base + 2 * TILE;
+  half_t* vtile = reinterpret_cast<half_t*>(smem) + wid * (64 * LDS_STRIDE);
   const int g = lane >> 4, c = lane & 15;
   const int q0 = qb * 64;
-  load_tile<64>(qtile, q + (long)q0 * ld, L - q0, ld, lane);
+  h8 qf[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[t][ks] = gfrag_clamped(q, q0 + t * 16, ks, L, ld, lane);
   float m[4], l[4];
-  f4 acc[4][4];
+  f4 acc[4][4];                                  // [d-tile][query tile]
 #pragma unroll
   for (int qt = 0; qt < 4; ++qt) {
     m[qt] = -INFINITY; l[qt] = 0.f;
@@ -117,23 +161,39 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(AttnArgs p) {
   const int nkb = p.causal ? qb + 1 : nqb;
   for (int kb = 0; kb < nkb; ++kb) {
     const int k0 = kb * 64;
-    load_tile<64>(ktile, k + (long)k0 * ld, L - k0, ld, lane);
-    load_tile<64>(vtile, v + (long)k0 * ld, L - k0, ld, lane);
-    f4 s[4][4];
-    st_block(ktile, qtile, s, lane);
-    h4 pt[4][4];
+    h8 kf[4][2], vf[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kf[t][ks] = gfrag_clamped(k, k0 + t * 16, ks, L, ld, lane);
+        vf[t][ks] = gfrag_clamped(v, k0 + t * 16, ks, L, ld, lane);
+      }
+    frags_to_tile(vtile, vf, lane);
+    h8 vT[4][2];                                 // V^T fragments, k-order permuted like the P^T accumulators
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) vT[dt][ks] = tr_frag(vtile, ks * 32, ks * 32 + 16, dt * 16, lane);
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       const int qi = q0 + qt * 16 + c;
+      f4 s[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][0], qf[qt][0], z, 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][1], qf[qt][1], s[kt], 0, 0, 0);
+      }
       float bm = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int key = k0 + kt * 16 + 4 * g + r;
-          bool ok = key < L && (!p.causal || key <= qi || qi >= L);
-          float val = ok ? s[kt][qt][r] * 0.125f : -INFINITY;
-          s[kt][qt][r] = val;
+          const int key = k0 + kt * 16 + 4 * g + r;
+          const bool ok = key < L && (!p.causal || key <= qi || qi >= L);
+          const float val = ok ? s[kt][r] * 0.125f : -INFINITY;
+          s[kt][r] = val;
           bm = fmaxf(bm, val);
         }
       bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
@@ -141,12 +201,13 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(AttnArgs p) {
       const float mn = fmaxf(m[qt], bm);
       const float alpha = (mn == -INFINITY) ? 1.f : __expf(m[qt] - mn);
       float sum = 0.f;
+      h4 pt[4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float e = (mn == -INFINITY) ? 0.f : __expf(s[kt][qt][r] - mn);
-          pt[kt][qt][r] = (half_t)e;
+          const float e = (mn == -INFINITY) ? 0.f : __expf(s[kt][r] - mn);
+          pt[kt][r] = (half_t)e;
           sum += e;
         }
       sum += __shfl_xor(sum, 16, 64);
@@ -154,9 +215,14 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(AttnArgs p) {
       l[qt] = l[qt] * alpha + sum;
       m[qt] = mn;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc[dt][qt] *= alpha;
+      for (int dt = 0; dt < 4; ++dt) {
+        f4 a = acc[dt][qt] * alpha;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(vT[dt][ks], cat4(pt[2 * ks], pt[2 * ks + 1]), a, 0, 0, 0);
+        acc[dt][qt] = a;
+      }
     }
-    acc_tr_regs(vtile, pt, acc, lane);
   }
   half_t* o = p.out + (long)n * L * D + h * DH;
 #pragma unroll
@@ -164,10 +230,11 @@ __global__ __launch_bounds__(256) void attn_long_fwd_kernel(AttnArgs p) {
     const int qi = q0 + qt * 16 + c;
     const float inv = 1.0f / l[qt];
     if (g == 0 && qi < L) p.lse[((long)n * p.H + h) * L + qi] = m[qt] + __logf(l[qt]);
+    f4 t[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt][qt] *= inv;
+    for (int dt = 0; dt < 4; ++dt) t[dt] = acc[dt][qt] * inv;
+    store_row16(o, D, t, qi, qi < L, lane);
   }
-  store_t(o, D, q0, L, acc, lane);
 }
 
 // recompute P^T and dS^T of one (query block, key block) from LDS tiles and the saved row statistics
@@ -285,9 +352,7 @@ __global__ __launch_bounds__(64) void attn_long_bwd_kernel(AttnArgs p) {
 int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream) {
   const int nqb = (p.L + 63) / 64;
   long waves = (long)p.nseq * p.H * nqb;
-  const int lds = 4 * 3 * TILE * 2;
-  static bool once = (hmmc_allow_lds((const void*)attn_long_fwd_kernel, lds), true);
-  (void)once;
+  const int lds = 4 * 64 * LDS_STRIDE * 2;
   hipLaunchKernelGGL(attn_long_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, stream, p);
   return hmmc_launch_status();
 }
