@@ -237,40 +237,42 @@ __global__ __launch_bounds__(256, 2) void attn_long_fwd_kernel(AttnArgs p) {
   }
 }
 
-// recompute P^T and dS^T of one (query block, key block) from LDS tiles and the saved row statistics
-__device__ __forceinline__ void pds_block(const half_t* ktile, const half_t* vtile, const half_t* qtile, const half_t* dotile,
-                                          const float* lse, const float* delta, int q0, int k0, int L, int causal,
-                                          h4 (&pt)[4][4], h4 (&dst)[4][4], int lane) {
-  const int g = lane >> 4, c = lane & 15;
-  f4 s[4][4], dp[4][4];
-  st_block(ktile, qtile, s, lane);
-  st_block(vtile, dotile, dp, lane);
+// Backward: one wave per (sequence, head, 64-row block, role).  role 0: dQ of a query block (loops over key blocks);
+// role 1: dV of a key block, role 2: dK of a key block (loop over query blocks).  Every role recomputes the probabilities it
+// needs from the saved log-sum-exp (8 MFMA units per block pair instead of the minimal 5) and in exchange holds only its
+// own 64 accumulator registers, keeps all operand rows as register fragments and needs one 9 KiB LDS tile for the
+// transposed operand - the layout of attention_f16.hip's one-block kernel - so 8 waves per CU are resident where the
+// previous one-wave-per-head kernel had 3.  delta[q] = <dO[q], O[q]> is recomputed per query block from the fragments.
+// Rows past L are clamped, never masked: their probabilities are forced to zero (lse = +inf for queries, key mask).
+__device__ __forceinline__ void delta_of_block(const h8 (&df)[4][2], const half_t* o, int q0, int L, int D, int lane,
+                                               float (&delta_c)[4]) {
 #pragma unroll
   for (int qt = 0; qt < 4; ++qt) {
-    const int ql = qt * 16 + c, qi = q0 + ql;
-    const float ls = lse[q0 + ql], de = delta[q0 + ql];
+    const h8 o0 = gfrag_clamped(o, q0 + qt * 16, 0, L, D, lane), o1 = gfrag_clamped(o, q0 + qt * 16, 1, L, D, lane);
+    float d = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = k0 + kt * 16 + 4 * g + r;
-        bool ok = key < L && qi < L && (!causal || key <= qi);
-        float pv = ok ? __expf(s[kt][qt][r] * 0.125f - ls) : 0.f;
-        pt[kt][qt][r] = (half_t)pv;
-        dst[kt][qt][r] = (half_t)(pv * (dp[kt][qt][r] - de) * 0.125f);
-      }
+    for (int j = 0; j < 8; ++j) d += (float)df[qt][0][j] * (float)o0[j] + (float)df[qt][1][j] * (float)o1[j];
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    delta_c[qt] = d;                              // query q0 + qt*16 + (lane & 15)
   }
 }
 
-// one wave per (sequence, head): phase 0 row statistics, phase 1 dK/dV per key block, phase 2 dQ per query block
-__global__ __launch_bounds__(64) void attn_long_bwd_kernel(AttnArgs p) {
+template <int ROLE>
+__global__ __launch_bounds__(256, 2) void attn_long_bwd_kernel(AttnArgs p) {
+  constexpr int WAVE_LDS = 64 * LDS_STRIDE * 2 + 2 * 64 * 4;      // tile + lse[64] + delta[64]
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x;
-  const long pair = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nb = (p.L + 63) / 64;
+  const long idx = (long)blockIdx.x * 4 + wid;
+  if (idx >= (long)p.nseq * p.H * nb) return;
+  constexpr int role = ROLE;
+  const int blk = (int)(idx % nb);
+  const long pair = idx / nb;
   const int n = (int)(pair / p.H), h = (int)(pair % p.H);
   const int D = p.H * DH, L = p.L;
   const long ld = 3L * D;
-  const int nb = (L + 63) / 64;
   const half_t* q = p.qkv + (long)n * L * ld + h * DH;
   const half_t* k = q + D;
   const half_t* v = q + 2 * D;
@@ -279,71 +281,169 @@ __global__ __launch_bounds__(64) void attn_long_bwd_kernel(AttnArgs p) {
   half_t* dq = p.dqkv + (long)n * L * ld + h * DH;
   half_t* dk = dq + D;
   half_t* dv = dq + 2 * D;
-  half_t* base = reinterpret_cast<half_t*>(smem);
-  half_t* ktile = base; half_t* vtile = base + TILE; half_t* qtile = base + 2 * TILE; half_t* dotile = base + 3 * TILE;
-  half_t* ytile = base + 4 * TILE;
-  float* lse = reinterpret_cast<float*>(base + 5 * TILE);
-  float* delta = lse + 256;
-  // phase 0: delta[q] = <dO[q], O[q]>, lse[q]
-  for (int r = lane; r < 256; r += 64) {
-    float d = 0.f;
-    if (r < L) {
-      const half_t* a = dO + (long)r * D;
-      const half_t* b = o + (long)r * D;
+  half_t* xt = reinterpret_cast<half_t*>(smem + wid * WAVE_LDS);
+  float* lse_s = reinterpret_cast<float*>(smem + wid * WAVE_LDS + 64 * LDS_STRIDE * 2);
+  float* del_s = lse_s + 64;
+  const int g = lane >> 4, c = lane & 15;
+  const float* lse_g = p.lse + ((long)n * p.H + h) * L;
+
+  if constexpr (role == 0) {
+    // ---- dQ[q0 .. q0+63]: keys on the lane's rows, this block's queries on its columns
+    const int q0 = blk * 64;
+    h8 qf[4][2], df[4][2];
 #pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
-        h8 x = *reinterpret_cast<const h8*>(a + ch * 8), y = *reinterpret_cast<const h8*>(b + ch * 8);
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d += (float)x[e] * (float)y[e];
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[t][ks] = gfrag_clamped(q, q0 + t * 16, ks, L, ld, lane);
+        df[t][ks] = gfrag_clamped(dO, q0 + t * 16, ks, L, D, lane);
       }
-    }
-    delta[r] = d;
-    lse[r] = r < L ? p.lse[((long)n * p.H + h) * L + r] : 0.f;
-  }
-  // phase 1: dK, dV
-  for (int kb = 0; kb < nb; ++kb) {
-    const int k0 = kb * 64;
-    load_tile<64>(ktile, k + (long)k0 * ld, L - k0, ld, lane);
-    load_tile<64>(vtile, v + (long)k0 * ld, L - k0, ld, lane);
-    f4 dka[4][4], dva[4][4];
+    float lse_c[4], delta_c[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) lse_c[t] = (q0 + t * 16 + c < L) ? lse_g[q0 + t * 16 + c] : INFINITY;
+    delta_of_block(df, o, q0, L, D, lane, delta_c);
+    f4 acc[4][4];                                // [query tile][d-tile]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { dka[i][j] = f4{0.f, 0.f, 0.f, 0.f}; dva[i][j] = f4{0.f, 0.f, 0.f, 0.f}; }
-    for (int qb = p.causal ? kb : 0; qb < nb; ++qb) {
-      const int q0 = qb * 64;
-      load_tile<64>(qtile, q + (long)q0 * ld, L - q0, ld, lane);
-      load_tile<64>(dotile, dO + (long)q0 * D, L - q0, D, lane);
-      h4 pt[4][4], dst[4][4];
-      pds_block(ktile, vtile, qtile, dotile, lse, delta, q0, k0, L, p.causal, pt, dst, lane);
-      stage_t(ytile, pt, lane);
-      acc_tr_lds(dotile, ytile, dva, lane);
-      stage_t(ytile, dst, lane);
-      acc_tr_lds(qtile, ytile, dka, lane);
-    }
-    store_t(dv, ld, k0, L, dva, lane);
-    store_t(dk, ld, k0, L, dka, lane);
-  }
-  // phase 2: dQ
-  for (int qb = 0; qb < nb; ++qb) {
-    const int q0 = qb * 64;
-    load_tile<64>(qtile, q + (long)q0 * ld, L - q0, ld, lane);
-    load_tile<64>(dotile, dO + (long)q0 * D, L - q0, D, lane);
-    f4 dqa[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dqa[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    const int nkb = p.causal ? qb + 1 : nb;
+      for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const int nkb = p.causal ? blk + 1 : nb;
     for (int kb = 0; kb < nkb; ++kb) {
       const int k0 = kb * 64;
-      load_tile<64>(ktile, k + (long)k0 * ld, L - k0, ld, lane);
-      load_tile<64>(vtile, v + (long)k0 * ld, L - k0, ld, lane);
-      h4 pt[4][4], dst[4][4];
-      pds_block(ktile, vtile, qtile, dotile, lse, delta, q0, k0, L, p.causal, pt, dst, lane);
-      acc_tr_regs(ktile, dst, dqa, lane);
+      h8 kf[4][2], vf[4][2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          kf[t][ks] = gfrag_clamped(k, k0 + t * 16, ks, L, ld, lane);
+          vf[t][ks] = gfrag_clamped(v, k0 + t * 16, ks, L, ld, lane);
+        }
+      frags_to_tile(xt, kf, lane);
+      h8 kT[4][2];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kT[dt][ks] = tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane);
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        const int qi = q0 + qt * 16 + c;
+        h4 ds16[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          f4 z = {0.f, 0.f, 0.f, 0.f};
+          f4 sv = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][0], qf[qt][0], z, 0, 0, 0);
+          sv = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][1], qf[qt][1], sv, 0, 0, 0);
+          f4 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[kt][0], df[qt][0], z, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[kt][1], df[qt][1], dp, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = k0 + kt * 16 + 4 * g + r;
+            float pv = __expf(sv[r] * 0.125f - lse_c[qt]);
+            pv = (key < L && (!p.causal || key <= qi)) ? pv : 0.f;
+            ds16[kt][r] = (half_t)(pv * (dp[r] - delta_c[qt]) * 0.125f);
+          }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kT[dt][ks], cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[qt][dt], 0, 0, 0);
+      }
     }
-    store_t(dq, ld, q0, L, dqa, lane);
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const int qi = q0 + qt * 16 + c;
+      store_row16(dq, ld, acc[qt], qi, qi < L, lane);
+    }
+  } else {
+  // ---- dV (role 1) / dK (role 2) of keys k0 .. k0+63: queries on the lane's rows, this block's keys on its columns
+  const int k0 = blk * 64;
+  constexpr bool want_dk = role == 2;
+  h8 kf[4][2], vf[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[t][ks] = gfrag_clamped(k, k0 + t * 16, ks, L, ld, lane);
+      if constexpr (want_dk) vf[t][ks] = gfrag_clamped(v, k0 + t * 16, ks, L, ld, lane);
+    }
+  f4 acc[4][4];                                  // [key tile][d-tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int qb = p.causal ? blk : 0; qb < nb; ++qb) {
+    const int q0 = qb * 64;
+    h8 qf[4][2], df[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[t][ks] = gfrag_clamped(q, q0 + t * 16, ks, L, ld, lane);
+        df[t][ks] = gfrag_clamped(dO, q0 + t * 16, ks, L, D, lane);
+      }
+    // row statistics of this query block, redistributed through LDS from "query on the column" to "query on the row"
+    if (g == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) lse_s[t * 16 + c] = (q0 + t * 16 + c < L) ? lse_g[q0 + t * 16 + c] : INFINITY;
+    }
+    if constexpr (want_dk) {
+      float delta_c[4];
+      delta_of_block(df, o, q0, L, D, lane, delta_c);
+      if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) del_s[t * 16 + c] = delta_c[t];
+      }
+    }
+    // transposed operand of the output product: dO^T for dV, Q^T for dK
+    frags_to_tile(xt, want_dk ? qf : df, lane);
+    h8 xT[4][2];                                 // dV holds the transposed fragments; dK (more live operands) re-reads them per key tile
+    if constexpr (!want_dk) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xT[dt][ks] = tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int key = k0 + kt * 16 + c;
+      if constexpr (want_dk) asm volatile("" ::: "memory");      // re-read the row statistics per key tile instead of holding 32 VGPRs
+      h4 y16[4];                                 // P^T (dV) or dS^T (dK) of this key tile, per query tile
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+        f4 sv = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qt][0], kf[kt][0], z, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qt][1], kf[kt][1], sv, 0, 0, 0);
+        f4 dp = z;
+        if constexpr (want_dk) {
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[qt][0], vf[kt][0], z, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[qt][1], vf[kt][1], dp, 0, 0, 0);
+        }
+        const f4 lr = *reinterpret_cast<const f4*>(lse_s + qt * 16 + 4 * g);
+        f4 dr = z;
+        if constexpr (want_dk) dr = *reinterpret_cast<const f4*>(del_s + qt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = q0 + qt * 16 + 4 * g + r;
+          float pv = __expf(sv[r] * 0.125f - lr[r]);
+          pv = (key < L && (!p.causal || key <= qi)) ? pv : 0.f;
+          y16[qt][r] = want_dk ? (half_t)(pv * (dp[r] - dr[r]) * 0.125f) : (half_t)pv;
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          acc[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(want_dk ? tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane) : xT[dt][ks],
+                                                               cat4(y16[2 * ks], y16[2 * ks + 1]), acc[kt][dt], 0, 0, 0);
+    }
+  }
+  half_t* dst = want_dk ? dk : dv;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int key = k0 + kt * 16 + c;
+    store_row16(dst, ld, acc[kt], key, key < L, lane);
+  }
   }
 }
 
@@ -358,9 +458,12 @@ int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream) {
 }
 
 int hmmc_attention_long_bwd(const AttnArgs& p, hipStream_t stream) {
-  const int lds = 5 * TILE * 2 + 2 * 256 * 4;
-  static bool once = (hmmc_allow_lds((const void*)attn_long_bwd_kernel, lds), true);
-  (void)once;
-  hipLaunchKernelGGL(attn_long_bwd_kernel, dim3((unsigned)((long)p.nseq * p.H)), dim3(64), lds, stream, p);
+  const int nb = (p.L + 63) / 64;
+  const long waves = (long)p.nseq * p.H * nb;
+  const int lds = 4 * (64 * LDS_STRIDE * 2 + 2 * 64 * 4);
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  hipLaunchKernelGGL(attn_long_bwd_kernel<2>, grid, block, lds, stream, p);     // dK (the longest role) first
+  hipLaunchKernelGGL(attn_long_bwd_kernel<0>, grid, block, lds, stream, p);     // dQ
+  hipLaunchKernelGGL(attn_long_bwd_kernel<1>, grid, block, lds, stream, p);     // dV
   return hmmc_launch_status();
 }
