@@ -1,89 +1,11 @@
-// Fused attention for sequences of 65..256 tokens (ViT-B/16: 197 tokens per frame; CLIP text up to 77):
-// the same "key on the row, query on the column" MFMA orientation as attention_f16.hip, tiled 64 x 64 with an
-// online softmax over key blocks (forward) and block-wise recomputation from the saved log-sum-exp (backward).
-// One wave owns one (sequence, head[, query block]); all LDS is wave-private, no workgroup barriers.
+// Fused attention for sequences of 65..256 tokens (ViT-B/16: 197 tokens per frame; CLIP text up to 77): the same
+// "key on the row, query on the column" MFMA orientation and register-fragment layout as attention_f16.hip, in blocks of
+// 64 x 64 with an online softmax over key blocks (forward) and block-wise recomputation from the saved log-sum-exp
+// (backward).  One wave owns one (sequence, head, 64-row block[, role]); all LDS is wave-private, no workgroup barriers.
 // Reference: nn.MultiheadAttention core at modules/module_clip.py:251 with 197 x 197 heads.
 #include "attn_common.h"
 
 namespace {
-
-constexpr int TILE = 64 * LDS_STRIDE;      // halves per 64-row LDS tile
-
-// S^T block [4 key tiles][4 query tiles] = K_blk Q_blk^T with K and Q rows read from LDS tiles
-__device__ __forceinline__ void st_block(const half_t* ktile, const half_t* qtile, f4 (&s)[4][4], int lane) {
-  const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    const half_t* qr = qtile + (qt * 16 + c) * LDS_STRIDE + 8 * g;
-    h8 q0 = *reinterpret_cast<const h8*>(qr), q1 = *reinterpret_cast<const h8*>(qr + 32);
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const half_t* kr = ktile + (kt * 16 + c) * LDS_STRIDE + 8 * g;
-      h8 k0 = *reinterpret_cast<const h8*>(kr), k1 = *reinterpret_cast<const h8*>(kr + 32);
-      f4 a = {0.f, 0.f, 0.f, 0.f};
-      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, q0, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, q1, a, 0, 0, 0);
-      s[kt][qt] = a;
-    }
-  }
-}
-
-// acc[dt][col tile] += X^T[d][k] * Y[k][col]: X from an LDS tile via transposed reads, Y from registers
-// (k order: tiles 2s, 2s+1 interleaved as produced by the accumulator layout)
-__device__ __forceinline__ void acc_tr_regs(const half_t* xtile, const h4 (&y)[4][4], f4 (&acc)[4][4], int lane) {
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    h8 x0 = tr_frag(xtile, 0, 16, dt * 16, lane), x1 = tr_frag(xtile, 32, 48, dt * 16, lane);
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      acc[dt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x0, cat4(y[0][ct], y[1][ct]), acc[dt][ct], 0, 0, 0);
-      acc[dt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x1, cat4(y[2][ct], y[3][ct]), acc[dt][ct], 0, 0, 0);
-    }
-  }
-}
-
-// acc[dt][kt] += X^T[d][q] * Y[q][key]: X via transposed reads, Y staged in LDS as [key][q]
-__device__ __forceinline__ void acc_tr_lds(const half_t* xtile, const half_t* ytile, f4 (&acc)[4][4], int lane) {
-  const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    h8 x0 = tr_frag(xtile, 0, 16, dt * 16, lane), x1 = tr_frag(xtile, 32, 48, dt * 16, lane);
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const half_t* yr = ytile + (kt * 16 + c) * LDS_STRIDE + 4 * g;
-      h4 a0 = *reinterpret_cast<const h4*>(yr), a1 = *reinterpret_cast<const h4*>(yr + 16);
-      h4 b0 = *reinterpret_cast<const h4*>(yr + 32), b1 = *reinterpret_cast<const h4*>(yr + 48);
-      acc[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x0, cat4(a0, a1), acc[dt][kt], 0, 0, 0);
-      acc[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x1, cat4(b0, b1), acc[dt][kt], 0, 0, 0);
-    }
-  }
-}
-
-__device__ __forceinline__ void stage_t(half_t* ytile, const h4 (&v)[4][4], int lane) {
-  const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ytile[(kt * 16 + 4 * g + r) * LDS_STRIDE + qt * 16 + c] = v[kt][qt][r];
-}
-
-__device__ __forceinline__ void store_t(half_t* dst, long ld, int row0, int L, const f4 (&acc)[4][4], int lane) {
-  const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      int row = row0 + ct * 16 + c;
-      if (row < L) {
-        h4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)acc[dt][ct][r];
-        *reinterpret_cast<h4*>(dst + (long)row * ld + dt * 16 + 4 * g) = o;
-      }
-    }
-}
 
 // ---- register-fragment helpers (the layout of attention_f16.hip: operand rows straight from global memory into MFMA
 // fragments, one 9 KiB LDS tile per wave for the transposed operand) -----------------------------------------------------

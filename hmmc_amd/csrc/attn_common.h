@@ -31,30 +31,6 @@ __device__ __forceinline__ h8 cat4(h4 a, h4 b) {
   return r;
 }
 
-// copy a [L][64] head slice (row stride ld halves) into an LDS tile [LP][LDS_STRIDE], zero rows >= L
-template <int LP>
-__device__ __forceinline__ void load_tile(half_t* tile, const half_t* src, int L, long ld, int lane) {
-#pragma unroll
-  for (int ps = 0; ps < LP / 8; ++ps) {
-    int row = ps * 8 + (lane >> 3), ch = lane & 7;
-    h8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
-    if (row < L) v = *reinterpret_cast<const h8*>(src + (long)row * ld + ch * 8);
-    *reinterpret_cast<h8*>(tile + row * LDS_STRIDE + ch * 8) = v;
-  }
-}
-
-// fragment of a row-major [rows][64] global slice: 8 halves X[row0 + (lane&15)][ks*32 + 8*(lane>>4) + j]
-__device__ __forceinline__ h8 gfrag(const half_t* src, int row0, int ks, int L, long ld, int lane) {
-  int row = row0 + (lane & 15);
-  h8 v;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
-  if (row < L) v = *reinterpret_cast<const h8*>(src + (long)row * ld + ks * 32 + 8 * (lane >> 4));
-  return v;
-}
-
 // transposed fragment from an LDS tile [r][c] (stride LDS_STRIDE): 8 halves T[kperm][c0 + (lane&15)]
 // with rows r = rA + 4*(lane>>4) + j (j<4) and rB + 4*(lane>>4) + (j-4) (j>=4)
 __device__ __forceinline__ h8 tr_frag(const half_t* tile, int rA, int rB, int c0, int lane) {
