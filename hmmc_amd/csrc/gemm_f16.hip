@@ -25,6 +25,10 @@
 #include "common.h"
 #include <cstdlib>
 
+#ifndef HMMC_DBG
+#define HMMC_DBG 0   // diagnostics (scratch/): 1 no global stores, 2 no epilogue (wrong results; timing only)
+#endif
+
 namespace {
 
 constexpr int BKT = 64;
@@ -131,53 +135,27 @@ __device__ __forceinline__ h8 read_frag(const char* lds_tile, int row0, int ks, 
 
 // ---- epilogue -------------------------------------------------------------------------------------
 // MFMA layout: lane (c = lane & 15, g = lane >> 4) owns C[m0 + c][16j + 4g .. +3] of every 16x16 tile j: four
-// 8-byte pieces per row.  Stored like that an instruction touches 16 rows x 32 B; measured per-CU store rates
-// (scratch/ubench/store_bw.hip): 8 rows x 128 B per instruction 130 GB/s, 16 rows x 64 B 33 GB/s.  Two register
-// exchanges bring the strip into the 8 x 128 B shape without touching LDS:
-//  1. v_permlane16_swap (odd 16-lane rows of one register <-> even rows of another) applied to (piece j = 2q,
-//     piece j = 2q + 1) hands every lane its neighbour's (g ^ 1) piece of the same tile: the lane then holds 8
-//     consecutive columns, 16 bytes, per column pair q, at column offset 32q + 16 (g & 1) + 8 (g >> 1).
-//  2. a DPP row rotate by 8 swaps q = 1 of rows c < 8 with q = 0 of rows c >= 8: afterwards lanes c < 8 hold the
-//     q = 0 pieces of rows c and c + 8, lanes c >= 8 the q = 1 pieces of rows c - 8 and c.  Store t = 0, 1 writes
-//     rows 8t .. 8t + 7, each row's 128 bytes from 8 lanes.
-// Both exchanges are involutions, so the residual / pre-activation operand is read with the same full-line
-// accesses and brought back into the MFMA layout.  All operand loads of the tile are issued before the first strip is
-// processed; nothing waits between strips.
-__device__ __forceinline__ void swap_rows(unsigned& x, unsigned& y) {
-  auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
-  x = r[0]; y = r[1];
-}
+// 8-byte pieces per row, and 16 consecutive lanes hold 16 different rows.  The memory pipeline coalesces a
+// wave-instruction over CONSECUTIVE lanes: the same 8 rows x 128 B written with lanes in that order take 3.4x as long as
+// with lane l on row l >> 3, bytes 16 (l & 7) .. +15 (scratch/ubench/burst_store.hip: 3.7 us against 1.1 us per 256x256 tile
+// per CU; in the kernel the stores were 4.6 us of every work item, whatever the cache policy and whether the lines were
+// in L2 or not).  So every 16-row strip goes through a 2 KiB per-wave LDS tile: written from the MFMA layout with
+// ds_write_b64, read back one full row per 8 lanes with ds_read_b128, and stored / loaded in that order.  A wave's LDS
+// operations execute in order, so neither a barrier nor a wait separates a strip's writes from its reads or one strip
+// from the next; rows are 128 B with the 16-byte chunk index XORed by key(row) = (row & 7) ^ (row >> 3), which makes
+// both the 8-byte writes and the 16-byte reads bank-conflict free.  The residual / auxiliary operand takes the same
+// path backwards (full-line loads in lane order -> LDS -> MFMA layout) through a second tile.
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
+constexpr int EPI_LDS_PER_WAVE = 4096;            // two 16 x 128 B tiles: results, operands
+
 // two fp32 values -> one dword of two fp16 (round to nearest even): v_cvt_pk_f16_f32
 __device__ __forceinline__ unsigned pk2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, h2v));
-}
-// the MFMA-layout values of tiles 2q and 2q+1 of one strip (fp32, still to be rounded) -> the 16-byte piece
-__device__ __forceinline__ u4 pack_pair(const f4& t0, const f4& t1) {
-  return u4{pk2(t0[0], t0[1]), pk2(t0[2], t0[3]), pk2(t1[0], t1[1]), pk2(t1[2], t1[3])};
-}
-// piece of tile 2q and piece of tile 2q+1 (MFMA layout)  <->  8 consecutive columns of the lane's row
-__device__ __forceinline__ void swap_pair(u4& v) {
-  unsigned a = v[0], b = v[1], c = v[2], d = v[3];
-  swap_rows(a, c);
-  swap_rows(b, d);
-  v = u4{a, b, c, d};
-}
-// (x = q0 piece, y = q1 piece) of this lane's row  <->  the lane's two 16-byte pieces in store order.
-// row_ror:8 reads lane c ^ 8 of the same 16-lane row; the bank mask picks which half of the row is written:
-// lanes c >= 8 take the neighbour's y into x, lanes c < 8 the neighbour's x into y.
-__device__ __forceinline__ void to_store_order(u4& x, u4& y) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned x0 = x[e];
-    x[e] = (unsigned)__builtin_amdgcn_update_dpp((int)x[e], (int)y[e], 0x128, 0xf, 0xc, false);
-    y[e] = (unsigned)__builtin_amdgcn_update_dpp((int)y[e], (int)x0, 0x128, 0xf, 0x3, false);
-  }
 }
 __device__ __forceinline__ f4 unpack2(unsigned lo, unsigned hi) {
   h2v a = __builtin_bit_cast(h2v, lo), b = __builtin_bit_cast(h2v, hi);
@@ -185,17 +163,23 @@ __device__ __forceinline__ f4 unpack2(unsigned lo, unsigned hi) {
 }
 
 // F >= 0: the epilogue flags at compile time; F < 0: p.flags at run time.  FULL: interior tile, no masks anywhere.
+// scr: this wave's EPI_LDS_PER_WAVE bytes of LDS.
 template <int MT, int F, bool FULL>
-__device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
+__device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane, char* scr) {
   const int flags = F >= 0 ? (F & ~EPI_COLSUM) : (p.flags & ~EPI_COLSUM);
   const bool want_csum = F >= 0 ? (F & EPI_COLSUM) != 0 : p.csum != nullptr;
   const int c = lane & 15, g = lane >> 4;
-  const int n_l = 32 * (c >> 3) + 16 * (g & 1) + 8 * (g >> 1);   // this lane's 8 columns within the wave's 64
-  const bool n_ok = FULL || n0 + n_l < p.N;                      // N % 8 == 0: a 16-byte piece is all-in or all-out
-  const int r_l = c & 7;                                         // this lane's row within a group of 8
+  // MFMA side of the LDS tile: piece j of this lane at mf_off ^ (32 j)
+  const int mf_off = c * 128 + (((g >> 1) ^ ((c & 7) ^ (c >> 3))) << 4) + 8 * (g & 1);
+  // line side: lane l reads / writes row (l >> 3) + 8 t, chunk l & 7
+  const int r_l = lane >> 3, q_l = lane & 7;
+  const int ln_off0 = r_l * 128 + ((q_l ^ r_l) << 4);                  // key(r_l) = r_l for rows 0..7
+  const int ln_off1 = (r_l + 8) * 128 + ((q_l ^ r_l ^ 1) << 4);        // key(r_l + 8) = r_l ^ 1
+  const bool n_ok = FULL || n0 + 8 * q_l < p.N;                        // N % 8 == 0: a 16-byte piece is all-in or all-out
   // global address = uniform 64-bit base (scalar registers) + 32-bit lane offset
-  const unsigned voff = ((unsigned)r_l * (unsigned)p.ldc + (unsigned)n_l) * 2u;
-  const size_t row8 = (size_t)p.ldc * 16u;                       // bytes between row r and row r + 8
+  const unsigned voff = ((unsigned)r_l * (unsigned)p.ldc + (unsigned)(8 * q_l)) * 2u;
+  const size_t row8 = (size_t)p.ldc * 16u;                             // bytes between row r and row r + 8
+  char* const scr_in = scr + 2048;
   f4 bias[4];
   if (flags & EPI_BIAS) {
 #pragma unroll
@@ -213,48 +197,74 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
   f4 csum[4];                                    // EPI_COLSUM: column sums of the fp16 values written, over this wave's rows
 #pragma unroll
   for (int j = 0; j < 4; ++j) csum[j] = f4{0.f, 0.f, 0.f, 0.f};
-  auto store2 = [&](half_t* dst, int i, u4 o0, u4 o1) {
-    char* sb = reinterpret_cast<char*>(dst) + ((size_t)(m_base + 16 * i) * p.ldc + n0) * 2u;
+  auto load_strip = [&](int slot, int strip) {
+    const char* sb = src + ((size_t)(m_base + 16 * strip) * p.ldc + n0) * 2u;
     if (FULL) {
-      // streaming stores: a tile's output is next read by another kernel, long after the operand panels that the K loops
-      // keep re-reading from L2 have passed (per layer 6 877-7 019 -> 6 770 us in scratch/gemm_bench.py, step -0.5 %)
-      __builtin_nontemporal_store(o0, reinterpret_cast<u4*>(sb + voff));
-      __builtin_nontemporal_store(o1, reinterpret_cast<u4*>(sb + row8 + voff));
-    } else {
-      const int m0 = m_base + 16 * i + r_l;
-      if (m0 < p.M && n_ok) *reinterpret_cast<u4*>(sb + voff) = o0;
-      if (m0 + 8 < p.M && n_ok) *reinterpret_cast<u4*>(sb + row8 + voff) = o1;
+      rin[slot][0] = *reinterpret_cast<const u4*>(sb + voff);
+      rin[slot][1] = *reinterpret_cast<const u4*>(sb + row8 + voff);
+    } else {                                     // clamped, never masked: rows / columns outside are not stored
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int m = min(m_base + 16 * strip + 8 * t + r_l, p.M - 1);
+        rin[slot][t] = *reinterpret_cast<const u4*>(src + ((size_t)m * p.ldc + (n_ok ? n0 + 8 * q_l : 0)) * 2u);
+      }
     }
   };
+  // the four 8-byte pieces of a strip (MFMA layout) -> LDS -> the lane's two 16-byte row pieces -> global.  The global
+  // stores of a strip are issued after the LDS operations of the NEXT one, so a strip's LDS round trip is covered by its
+  // successor's arithmetic instead of being waited for.
+  u4 pv0, pv1;
+  half_t* pv_dst = nullptr;
+  int pv_i = 0;
+  bool have_prev = false;
+  auto flush = [&]() {
+    if (!have_prev) return;
+#if HMMC_DBG == 1
+    asm volatile("" :: "v"(pv0), "v"(pv1));
+    return;
+#endif
+    char* sb = reinterpret_cast<char*>(pv_dst) + ((size_t)(m_base + 16 * pv_i) * p.ldc + n0) * 2u;
+    if (FULL) {
+      // streaming stores: a tile's output is next read by another kernel, long after the operand panels that the K loops
+      // keep re-reading from L2 have passed
+      __builtin_nontemporal_store(pv0, reinterpret_cast<u4*>(sb + voff));
+      __builtin_nontemporal_store(pv1, reinterpret_cast<u4*>(sb + row8 + voff));
+    } else {
+      const int m0 = m_base + 16 * pv_i + r_l;
+      if (m0 < p.M && n_ok) *reinterpret_cast<u4*>(sb + voff) = pv0;
+      if (m0 + 8 < p.M && n_ok) *reinterpret_cast<u4*>(sb + row8 + voff) = pv1;
+    }
+  };
+  auto store_strip = [&](half_t* dst, int i, const u2 (&pc)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<u2*>(scr + (mf_off ^ (32 * j))) = pc[j];
+    const u4 o0 = *reinterpret_cast<const u4*>(scr + ln_off0);
+    const u4 o1 = *reinterpret_cast<const u4*>(scr + ln_off1);
+    flush();
+    pv0 = o0; pv1 = o1; pv_dst = dst; pv_i = i; have_prev = true;
+  };
+  // operand strip: full-line pieces (lane order) -> LDS -> the four 8-byte pieces of the MFMA layout, one strip ahead
+  u2 inr[2][4];
+  auto in_issue = [&](int i) {
+    *reinterpret_cast<u4*>(scr_in + ln_off0) = rin[i % HB][0];
+    *reinterpret_cast<u4*>(scr_in + ln_off1) = rin[i % HB][1];
+    // the slot is free again: request strip i + HB now, so the second half of the operand arrives while the first is processed
+    if (i + HB < MT) load_strip(i % HB, i + HB);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inr[i & 1][j] = *reinterpret_cast<const u2*>(scr_in + (mf_off ^ (32 * j)));
+  };
+  if (has_src) {
+#pragma unroll
+    for (int ii = 0; ii < HB; ++ii) load_strip(ii, ii);
+    in_issue(0);
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     f4 in[4];
     if (has_src) {
-      auto load_strip = [&](int slot, int strip) {
-        const char* sb = src + ((size_t)(m_base + 16 * strip) * p.ldc + n0) * 2u;
-        if (FULL) {
-          rin[slot][0] = *reinterpret_cast<const u4*>(sb + voff);
-          rin[slot][1] = *reinterpret_cast<const u4*>(sb + row8 + voff);
-        } else {                                 // clamped, never masked: rows / columns outside are not stored
+      if (i + 1 < MT) in_issue(i + 1);
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const int m = min(m_base + 16 * strip + 8 * t + r_l, p.M - 1);
-            rin[slot][t] = *reinterpret_cast<const u4*>(src + ((size_t)m * p.ldc + (n_ok ? n0 + n_l : 0)) * 2u);
-          }
-        }
-      };
-      if (i == 0) {
-#pragma unroll
-        for (int ii = 0; ii < HB; ++ii) load_strip(ii, ii);
-      }
-      u4 x = rin[i % HB][0], y = rin[i % HB][1];
-      // the slot is free again: request strip i + HB now, ahead of this strip's arithmetic and stores, so the second
-      // half of the operand arrives while the first half is being processed
-      if (i + HB < MT) load_strip(i % HB, i + HB);
-      to_store_order(x, y);                                      // involution: store order -> (q0, q1) of the own row
-      swap_pair(x); swap_pair(y);
-      in[0] = unpack2(x[0], x[1]); in[1] = unpack2(x[2], x[3]);
-      in[2] = unpack2(y[0], y[1]); in[3] = unpack2(y[2], y[3]);
+      for (int j = 0; j < 4; ++j) in[j] = unpack2(inr[i & 1][j][0], inr[i & 1][j][1]);
     }
     // out / pre hold the fp32 values whose rounding to fp16 is the result (the pack below rounds exactly once)
     f4 out[4], pre[4];
@@ -285,22 +295,25 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
         out[j] = v;
       }
     }
-    u4 o0 = pack_pair(out[0], out[1]), o1 = pack_pair(out[2], out[3]);
+    u2 pc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pc[j] = u2{pk2(out[j][0], out[j][1]), pk2(out[j][2], out[j][3])};
     if (want_csum) {                               // sums of the ROUNDED values, as a pass over the stored tensor would see
       const bool row_ok = FULL || m_base + 16 * i + c < p.M;
-      const f4 w0 = unpack2(o0[0], o0[1]), w1 = unpack2(o0[2], o0[3]), w2 = unpack2(o1[0], o1[1]), w3 = unpack2(o1[2], o1[3]);
-      if (row_ok) { csum[0] += w0; csum[1] += w1; csum[2] += w2; csum[3] += w3; }
+      if (row_ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) csum[j] += unpack2(pc[j][0], pc[j][1]);
+      }
     }
-    swap_pair(o0); swap_pair(o1);
-    to_store_order(o0, o1);
-    store2(p.C, i, o0, o1);
+    store_strip(p.C, i, pc);
     if (two) {                                   // the pre-activation, for the backward pass
-      u4 q0 = pack_pair(pre[0], pre[1]), q1 = pack_pair(pre[2], pre[3]);
-      swap_pair(q0); swap_pair(q1);
-      to_store_order(q0, q1);
-      store2(p.aux_out, i, q0, q1);
+      u2 qc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qc[j] = u2{pk2(pre[j][0], pre[j][1]), pk2(pre[j][2], pre[j][3])};
+      store_strip(p.aux_out, i, qc);
     }
   }
+  flush();
   if (want_csum) {                               // 16 lanes c -> one partial row per wave: row block (m_base / (16 MT))
     float* dst = p.csum + (size_t)(m_base / (16 * MT)) * p.N + n0;
 #pragma unroll
@@ -322,16 +335,16 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
 }
 
 template <int MT, int F>
-__device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
-  if (m_base + 16 * MT <= p.M && n0 + 64 <= p.N) epilogue_run<MT, F, true>(p, acc, m_base, n0, lane);    // wave-uniform
-  else epilogue_run<MT, F, false>(p, acc, m_base, n0, lane);
+__device__ __forceinline__ void epilogue_impl(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane, char* scr) {
+  if (m_base + 16 * MT <= p.M && n0 + 64 <= p.N) epilogue_run<MT, F, true>(p, acc, m_base, n0, lane, scr);    // wave-uniform
+  else epilogue_run<MT, F, false>(p, acc, m_base, n0, lane, scr);
 }
 
 // EPI >= 0: the kernel was instantiated for exactly these flags (straight-line epilogue, its own register budget);
 // EPI < 0: generic kernel, flags read at run time
 template <int MT, int EPI>
-__device__ __forceinline__ void epilogue_f16(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane) {
-  epilogue_impl<MT, EPI>(p, acc, m_base, n0, lane);
+__device__ __forceinline__ void epilogue_f16(const GemmArgs& p, f4 (&acc)[MT][4], int m_base, int n0, int lane, char* scr) {
+  epilogue_impl<MT, EPI>(p, acc, m_base, n0, lane, scr);
 }
 
 // split-K partial sums: fp32 slab [split][M][N], 16-byte stores straight from the MFMA layout
@@ -415,10 +428,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
   // writes the finished tile and clears the accumulators for the next item (a zero C operand on the first K-tile
   // instead of the clear measured 1-5 % slower: it doubles the MFMA blocks of the main loop)
   auto finish_item = [&]() {
+#if HMMC_DBG == 2
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(acc[i][j]));
+#else
     if (p.splitk > 1)
       epilogue_slab<MT, NT>(p, acc, tm * BM + wm * (MT * 16) + (lane & 15), tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
     else
-      epilogue_f16<MT, EPI>(p, acc, tm * BM + wm * (MT * 16), tn * BN + wn * (NT * 16), lane);
+      epilogue_f16<MT, EPI>(p, acc, tm * BM + wm * (MT * 16), tn * BN + wn * (NT * 16), lane, smem + 2 * STAGE_BYTES + wid * EPI_LDS_PER_WAVE);
+#endif
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -658,7 +675,7 @@ TileCfg pick_cfg(int M, int N, int K, bool allow_split) {
 
 template <bool AK, bool BK, int BM, int BN, int WM, int WN, int EPI>
 void launch_one(const GemmArgs& p, dim3 grid, hipStream_t stream) {
-  constexpr int SMEM = 2 * (BM + BN) * BKT * 2;
+  constexpr int SMEM = 2 * (BM + BN) * BKT * 2 + WM * WN * EPI_LDS_PER_WAVE;      // two stages + the epilogue's LDS tiles
   if (SMEM > 64 * 1024) {
     static bool once = (hmmc_allow_lds((const void*)gemm_f16_kernel<AK, BK, BM, BN, WM, WN, EPI>, SMEM), true);
     (void)once;
