@@ -31,8 +31,8 @@ SIGNATURES = {
     "hmmc_patchify_u8": ("ppiiiippp", "i"),
     "hmmc_patchify": ("ppiiiip", "i"),
     "hmmc_vit_embed": ("pppliip", "i"),
-    "hmmc_text_embed": ("ppppliip", "i"),
-    "hmmc_text_embed_bwd": ("ppplip", "i"),
+    "hmmc_text_embed": ("ppppliilpp", "i"),
+    "hmmc_text_embed_bwd": ("ppplilp", "i"),
     "hmmc_cast": ("pplip", "i"),
     "hmmc_attention_f16_fwd": ("pppiiiip", "i"),
     "hmmc_attention_f16_bwd": ("ppppppiiiip", "i"),

@@ -358,18 +358,24 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(half_t* __restrict__ x, 
 }
 
 // x[b][l][:] = fp16( fp16(table[ids[b][l]][:]) + fp16(pos[l][:]) )
+// ids outside [0, vocab) never index the table: the row is written as the position embedding alone and *err is set
+// (the reference's nn.Embedding raises an index error; a device kernel cannot, so the host checks the flag)
 __global__ __launch_bounds__(256) void text_embed_kernel(const long* __restrict__ ids, const float* __restrict__ table,
                                                          const float* __restrict__ pos, half_t* __restrict__ x,
-                                                         long rows, int L, int D) {
+                                                         long rows, int L, int D, long vocab, int* __restrict__ err) {
   const int dc = D / 8;
   const long total = rows * dc;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     int c = (int)(idx % dc);
     long row = idx / dc;
     int l = (int)(row % L);
-    const float* tr = table + ids[row] * (long)D + c * 8;
+    const long id = ids[row];
+    const bool ok = id >= 0 && id < vocab;
+    if (!ok && c == 0 && err) *err = 1;
+    const float* tr = table + (ok ? id : 0) * (long)D + c * 8;
     const float* pr = pos + (long)l * D + c * 8;
     f4 a = *reinterpret_cast<const f4*>(tr), b = *reinterpret_cast<const f4*>(tr + 4);
+    if (!ok) { a = f4{0.f, 0.f, 0.f, 0.f}; b = a; }
     f4 pa = *reinterpret_cast<const f4*>(pr), pb = *reinterpret_cast<const f4*>(pr + 4);
     h8 o;
 #pragma unroll
@@ -381,14 +387,71 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const long* __restrict_
   }
 }
 
-// dtable[ids[row]][:] += dx[row][:]   (fp32 table gradient, dense, zeroed by the caller)
-__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const long* __restrict__ ids, const half_t* __restrict__ dx,
-                                                             float* __restrict__ dtable, long rows, int D) {
-  const long total = rows * D;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long row = idx / D;
-    int d = (int)(idx - row * D);
-    atomicAdd(dtable + ids[row] * (long)D + d, (float)dx[idx]);
+// dtable[id][:] = sum over the rows r with ids[r] == id of dx[r][:]   (fp32 table gradient, dense, zeroed by the caller).
+// Deterministic, no atomics: one workgroup per token row; the row that is the FIRST occurrence of its id owns the id's
+// table row.  It lists the later occurrences in row order (wave ballots), its 8 waves each sum every 8th of them, and
+// the 8 partial sums are added in wave order: a fixed summation tree whatever the launch timing.  Ids that occur once
+// (most of them) cost one pass over the id list; the padding id's thousands of rows are 8 independent load chains.
+constexpr int TE_THREADS = 512, TE_WAVES = 8, TE_LIST = 16384;
+__global__ __launch_bounds__(TE_THREADS) void text_embed_bwd_kernel(const long* __restrict__ ids, const half_t* __restrict__ dx,
+                                                                    float* __restrict__ dtable, int rows, int D, long vocab) {
+  __shared__ unsigned short list[TE_LIST];
+  __shared__ int wave_cnt[TE_WAVES];
+  __shared__ int base_cnt;
+  __shared__ float part[TE_WAVES][512];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const long my = ids[r];
+  if (my < 0 || my >= vocab) return;                          // flagged by the forward pass; no gradient
+  for (int base = 0; base < r; base += TE_THREADS) {          // an earlier row with this id owns it
+    const int t = base + tid;
+    if (__syncthreads_or(t < r && ids[t] == my)) return;
+  }
+  for (int c0 = 0; c0 < D; c0 += 512) {                       // column blocks of 512 (one per text width of CLIP)
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    int start = r;
+    while (start < rows) {                                    // batches of at most TE_LIST occurrences
+      if (tid == 0) base_cnt = 0;
+      __syncthreads();
+      int next = rows;
+      for (int base = start; base < rows; base += TE_THREADS) {
+        const int t = base + tid;
+        const bool hit = t < rows && ids[t] == my;
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wave_cnt[wid] = __popcll(m);
+        __syncthreads();
+        int off = base_cnt, tot = 0;
+        for (int w = 0; w < TE_WAVES; ++w) { if (w < wid) off += wave_cnt[w]; tot += wave_cnt[w]; }
+        const bool room = base_cnt + tot <= TE_LIST;          // block-uniform
+        if (room && hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(t - start);
+        __syncthreads();
+        if (!room) { next = base; break; }
+        if (tid == 0) base_cnt += tot;
+        __syncthreads();
+      }
+      const int n = base_cnt;
+      const int col = c0 + lane * 8;
+      if (col < D) {
+        for (int i = wid; i < n; i += TE_WAVES) {
+          const h8 v = *reinterpret_cast<const h8*>(dx + (size_t)(start + list[i]) * D + col);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+      }
+      __syncthreads();
+      start = next;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[wid][lane * 8 + j] = acc[j];
+    __syncthreads();
+    if (c0 + tid < D) {
+      float s = part[0][tid];
+#pragma unroll
+      for (int w = 1; w < TE_WAVES; ++w) s += part[w][tid];
+      dtable[my * (long)D + c0 + tid] = s;
+    }
+    __syncthreads();
   }
 }
 
@@ -536,17 +599,19 @@ extern "C" int hmmc_vit_embed(void* x, const float* cls, const float* pos, long 
 }
 
 extern "C" int hmmc_text_embed(const long* ids, const float* table, const float* pos, void* x, long rows, int L, int D,
-                               hipStream_t stream) {
-  if (!ids || !table || !pos || !x || rows <= 0 || D % 8) return HMMC_ERR_ARG;
+                               long vocab, int* err_flag, hipStream_t stream) {
+  if (!ids || !table || !pos || !x || rows <= 0 || D % 8 || vocab <= 0) return HMMC_ERR_ARG;
   hipLaunchKernelGGL(text_embed_kernel, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, ids, table, pos,
-                     (half_t*)x, rows, L, D);
+                     (half_t*)x, rows, L, D, vocab, err_flag);
   return hmmc_launch_status();
 }
 
-extern "C" int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, hipStream_t stream) {
-  if (!ids || !dx || !dtable || rows <= 0) return HMMC_ERR_ARG;
-  hipLaunchKernelGGL(text_embed_bwd_kernel, dim3(grid_for(rows * D, 256, 4096)), dim3(256), 0, stream, ids,
-                     (const half_t*)dx, dtable, rows, D);
+extern "C" int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, long vocab,
+                                   hipStream_t stream) {
+  if (!ids || !dx || !dtable || rows <= 0 || vocab <= 0) return HMMC_ERR_ARG;
+  if (D % 8 || rows > 65535 + TE_THREADS) return HMMC_ERR_UNSUPPORTED;     // 16-bit row offsets within a batch of the list
+  hipLaunchKernelGGL(text_embed_bwd_kernel, dim3((unsigned)rows), dim3(TE_THREADS), 0, stream, ids, (const half_t*)dx, dtable,
+                     (int)rows, D, vocab);
   return hmmc_launch_status();
 }
 

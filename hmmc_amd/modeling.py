@@ -37,16 +37,21 @@ def _side_stream(device):
 class _AllGatherCat(torch.autograd.Function):
     """Differentiable all-gather along dim 0 (the reference uses diffdist.functional.all_gather,
     modules/modeling.py:25-36): forward = concat in rank order (one RCCL all-gather), backward = sum over
-    ranks of each rank's slice (one reduce-scatter)."""
+    ranks of each rank's slice (one reduce-scatter).  The collective is chosen ONCE from the backend's name, never by
+    catching an exception: a failed collective must propagate, not be followed by a different one on this rank alone."""
+
+    @staticmethod
+    def _flat():
+        return dist.get_backend() == "nccl"              # RCCL has the flat forms; gloo (CPU tests) does not
 
     @staticmethod
     def forward(ctx, x):
         x = x.contiguous()
         world = dist.get_world_size()
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        try:
+        if _AllGatherCat._flat():
             dist.all_gather_into_tensor(out, x)
-        except (RuntimeError, NotImplementedError):      # backends without the flat form (gloo + device tensors)
+        else:
             dist.all_gather(list(out.chunk(world, dim=0)), x)
         ctx.rows = x.shape[0]
         return out
@@ -54,15 +59,14 @@ class _AllGatherCat(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        rank = dist.get_rank()
-        gx = torch.empty((ctx.rows,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-        try:
+        if _AllGatherCat._flat():
+            gx = torch.empty((ctx.rows,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
             dist.reduce_scatter_tensor(gx, g, op=dist.ReduceOp.SUM)
-        except (RuntimeError, NotImplementedError):      # gloo: no reduce_scatter
-            g = g.clone()
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
-            gx = g[rank * ctx.rows:(rank + 1) * ctx.rows].contiguous()
-        return gx
+            return gx
+        rank = dist.get_rank()
+        g = g.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        return g[rank * ctx.rows:(rank + 1) * ctx.rows].contiguous()
 
 
 def dist_collect(x):
@@ -262,7 +266,9 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
         ids = input_ids.clone()
         labels = ids.clone()
         prob = torch.full(labels.shape, self.mlm_probability)
-        ids, labels = self.mask(ids, self.VOCAB, input_mask.device, targets=labels, probability_matrix=prob)
+        # random replacement ids are drawn from the rows the embedding table really has (VOCAB for CLIP's tokenizer)
+        vocab = self.text_encoder.token_embedding.weight.shape[0]
+        ids, labels = self.mask(ids, vocab, input_mask.device, targets=labels, probability_matrix=prob)
         hidden = self.text_encoder(ids, input_mask, return_hidden=True)
         return self.calculate_mlm_loss(hidden, labels)
 

@@ -216,7 +216,7 @@ def text_embed(ids, table, pos):
     b, L = ids.shape
     D = table.shape[1]
     x = torch.empty((b * L, D), dtype=torch.float16, device=ids.device)
-    call("hmmc_text_embed", ptr(ids), ptr(table), ptr(pos), ptr(x), b * L, L, D)
+    call("hmmc_text_embed", ptr(ids), ptr(table), ptr(pos), ptr(x), b * L, L, D, table.shape[0], ptr(device_error_flag(ids.device)))
     return x
 
 
@@ -224,8 +224,29 @@ def text_embed_bwd(ids, dx, vocab):
     _chk(dx, torch.float16, "dx")
     D = dx.shape[-1]
     dtable = torch.zeros((vocab, D), dtype=torch.float32, device=dx.device)
-    call("hmmc_text_embed_bwd", ptr(ids), ptr(dx), ptr(dtable), ids.numel(), D)
+    call("hmmc_text_embed_bwd", ptr(ids), ptr(dx), ptr(dtable), ids.numel(), D, vocab)
     return dtable
+
+
+_ERR_FLAGS = {}
+
+
+def device_error_flag(device):
+    """int32 [1] on `device` that kernels set instead of faulting (token ids outside the embedding table)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _ERR_FLAGS:
+        _ERR_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _ERR_FLAGS[key]
+
+
+def raise_on_device_errors(device=None):
+    """Synchronising check of the device error flags (what nn.Embedding's IndexError is in the reference)."""
+    keys = list(_ERR_FLAGS) if device is None else [torch.device(device).index or 0]
+    for k in keys:
+        f = _ERR_FLAGS.get(k)
+        if f is not None and int(f.item()) != 0:
+            f.zero_()
+            raise IndexError("token id outside the embedding table (hmmc_text_embed); the row was embedded as zeros")
 
 
 def attention_f16_fwd(qkv, nseq, L, H, causal):

@@ -94,11 +94,14 @@ int hmmc_patchify_u8(const void* img, void* out, int nframes, int H, int W, int 
 /* In place on the patch-GEMM output: class_embedding into row 0, + positional_embedding
  * (modules/module_clip.py:311-312), with the reference's fp16 rounding points. */
 int hmmc_vit_embed(void* x, const float* cls, const float* pos, long rows, int L, int D, hmmc_stream_t stream);
-/* token_embedding(ids).half() + positional_embedding[:L].half() (modules/module_cross.py:288-291). */
-int hmmc_text_embed(const long* ids, const float* table, const float* pos, void* x, long rows, int L, int D,
-                    hmmc_stream_t stream);
-/* dense fp32 embedding gradient: dtable[ids[r]] += dx[r] (dtable zeroed by the caller). */
-int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, hmmc_stream_t stream);
+/* token_embedding(ids).half() + positional_embedding[:L].half() (modules/module_cross.py:288-291).  An id outside
+ * [0, vocab) never indexes the table (the reference's nn.Embedding raises): its row is the position embedding alone and
+ * *err_flag (device int, may be NULL) is set to 1 for the host to check. */
+int hmmc_text_embed(const long* ids, const float* table, const float* pos, void* x, long rows, int L, int D, long vocab,
+                    int* err_flag, hmmc_stream_t stream);
+/* dense fp32 embedding gradient: dtable[id] = sum of dx[r] over the rows with ids[r] == id (dtable zeroed by the caller;
+ * ids outside [0, vocab) contribute nothing).  No atomics: bit-identical from run to run.  rows < 65536. */
+int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, long vocab, hmmc_stream_t stream);
 /* kind 0: fp16 -> fp32, 1: fp32 -> fp16 */
 int hmmc_cast(const void* in, void* out, long n, int kind, hmmc_stream_t stream);
 

@@ -59,3 +59,132 @@ def test_two_ranks_equal_single_process():
             assert cos > 0.995 and abs(ratio - 1) < 0.03, (k, cos, ratio)
     for k in KEYS:      # DDP left identical gradients on both ranks
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+# ----------------------------------------------------------------------------- pre-training, two ranks
+
+PT_KEYS = ["visual_encoder.visual.conv1.weight", "visual_encoder.visual.transformer.resblocks.0.attn.in_proj_weight",
+           "text_encoder.text_projection", "v_projector.linear_hidden.1.weight", "v_projector.linear_hidden.2.weight",
+           "v_predictor.linear_out.weight", "visual_encoder.temporal_transformer.resblocks.1.mlp.c_proj.weight",
+           "visual_encoder.frame_position_embeddings.weight"]
+PT_BUFFERS = ["queue_v_cross_ng", "queue_title_cross_ng", "queue_tag_cross_ng", "queue_frame_proj_ng", "queue_frame_cross_ng",
+              "queue_ptr", "v_projector.linear_hidden.2.running_mean", "v_projector.linear_hidden.2.running_var",
+              "v_predictor.linear_hidden.2.running_mean", "v_projector_k.linear_hidden.2.running_var",
+              "visual_encoder_k.visual.proj", "text_encoder_k.ln_final.weight"]
+
+
+def _run_pretrain(rank, world, store, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
+    from conftest import golden
+    from hmmc_amd.modeling import BirdPreTrainedModel
+    torch.cuda.set_device(0)
+    g = golden("moco_aswritten")
+    K, B, Fr = int(g["K"]), int(g["B"]), int(g["F"])
+    cfg = task_config(rank=rank, contrast_num_negative=K, max_frames=Fr, dataset="chvtt")
+    model = BirdPreTrainedModel.from_pretrained("cross-base", state_dict=synth.pretrain_state(synth.TINY, K, Fr),
+                                                task_config=cfg).cuda().train()
+    # t_projector is built, EMA'd and never used (reference modules/modeling.py:113-114): find_unused_parameters as main_pretrain.py:204
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True) if world > 1 else model
+    b = B // world
+    sl = slice(rank * b, (rank + 1) * b)
+    batch = synth.pretrain_batch(B, Fr, tag="moco.s0")
+    draws = [torch.from_numpy(g[f"mlm_{n}0"]) for n in ("masked", "replaced", "randsel", "words")]
+    model._mlm_draws = [d[sl] for d in draws]
+    title = batch[4][sl]
+    n_masked = int((draws[0][sl].bool() & (title != model.PAD_ID) & (title != model.CLS_ID)).sum())
+    loss = net(*[t[sl].cuda() for t in batch], 1)
+    loss.backward()
+    torch.cuda.synchronize()
+    P, S = dict(model.named_parameters()), model.state_dict()
+    out = {"loss": loss.detach().cpu(), "parts": [float(x) for x in model.last_losses], "n_masked": n_masked}
+    out.update({k: P[k].grad.float().cpu() for k in PT_KEYS})
+    out.update({k: S[k].float().cpu() for k in PT_BUFFERS})
+    torch.save(out, os.path.join(out_dir, f"p{world}r{rank}.pt"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_pretrain_two_ranks_equal_single_process():
+    """BirdPreTrainedModel under DDP on two ranks (B = 4 split 2 + 2): the packed key all-gather keeps the five queues and
+    queue_ptr identical on both ranks and equal to the single-process run, the BatchNorm statistics are those of all
+    ranks' rows (SyncBatchNorm, reference modules/modeling.py:115-129,244-284), and the averaged gradients are the
+    global-batch gradients."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_run_pretrain, args=(1, os.path.join(d, "s1"), d), nprocs=1, join=True)
+        mp.spawn(_run_pretrain, args=(2, os.path.join(d, "s2"), d), nprocs=2, join=True)
+        ref = torch.load(os.path.join(d, "p1r0.pt"))
+        outs = [torch.load(os.path.join(d, f"p2r{r}.pt")) for r in range(2)]
+    # FAM / VTM / FTM are means over a rank's rows: their average over the (equal-sized) ranks is the global mean
+    for i, nm in enumerate(("FAM", "VTM", "FTM")):
+        avg = 0.5 * (outs[0]["parts"][i] + outs[1]["parts"][i])
+        assert abs(avg - ref["parts"][i]) < 3e-3 * max(1.0, abs(ref["parts"][i])), (nm, avg, ref["parts"][i])
+    # MLM is a mean over a rank's masked tokens
+    n = [o["n_masked"] for o in outs]
+    assert sum(n) == ref["n_masked"] and min(n) > 0
+    mlm = (outs[0]["parts"][3] * n[0] + outs[1]["parts"][3] * n[1]) / sum(n)
+    assert abs(mlm - ref["parts"][3]) < 3e-3 * max(1.0, abs(ref["parts"][3])), (mlm, ref["parts"][3])
+    for k in PT_BUFFERS:
+        assert torch.equal(outs[0][k], outs[1][k]), f"{k} differs between the ranks"
+        tol = 0 if k == "queue_ptr" else 2e-3
+        err = float((outs[0][k] - ref[k]).abs().max())
+        assert err <= tol, f"{k}: two-rank run differs from the single process by {err}"
+    for k in PT_KEYS:
+        assert torch.equal(outs[0][k], outs[1][k]), f"DDP left different gradients for {k}"
+        a, b = outs[0][k].flatten(), ref[k].flatten()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-20))
+        ratio = float(a.norm() / (b.norm() + 1e-20))
+        assert cos > 0.99 and abs(ratio - 1) < 0.05, (k, cos, ratio)
+
+
+# ----------------------------------------------------------------------------- RCCL, one rank
+
+def _run_rccl(rank, out_dir, port):
+    """ProcessGroupNCCL (= RCCL) is initialised BEFORE anything touches the GPU in this fresh process."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from hmmc_amd import ops
+    from hmmc_amd.modeling import BirdModel
+    torch.cuda.set_device(0)
+    ops.reserve_cus_for_collectives()                      # what the towers do when they see world_size > 1
+    model = BirdModel.from_pretrained("cross-base", state_dict=synth.finetune_state(synth.TINY),
+                                      task_config=task_config(max_frames=6)).cuda().train()
+    for m in model.modules():
+        if hasattr(m, "ddp_layers_per_node"):
+            m.ddp_layers_per_node = 1                      # gradients reach DDP's bucket hooks layer by layer
+    batch = [t.cuda() for t in synth.finetune_batch(16, 6, 32, tag="det")]
+
+    def grads(net):
+        model.zero_grad(set_to_none=True)
+        loss = net(*batch, 1)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().cpu(), {n: p.grad.clone().cpu() for n, p in model.named_parameters() if p.grad is not None}
+
+    l0, g0 = grads(model)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, bucket_cap_mb=1)
+    l1, g1 = grads(ddp)
+    l2, g2 = grads(ddp)
+    torch.save({"l": (l0, l1, l2), "g": (g0, g1, g2)}, os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_ddp_is_bit_identical():
+    """DistributedDataParallel over the nccl backend (RCCL) with one rank: the bucketed all-reduces run on RCCL's stream
+    beside the text-tower, frame-tower and weight-gradient streams, with 16 CUs kept out of the GEMM grids.  A missing
+    dependency between a gradient's producer stream and its bucket's all-reduce would change bits here; with every
+    dependency in place the loss and every gradient equal the plain module's."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_run_rccl, args=(d, port), nprocs=1, join=True)
+        out = torch.load(os.path.join(d, "rccl.pt"))
+    (l0, l1, l2), (g0, g1, g2) = out["l"], out["g"]
+    assert float(l0) == float(l1) == float(l2), (float(l0), float(l1), float(l2))
+    assert set(g0) == set(g1) == set(g2)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), f"{n}: DDP over RCCL changed the gradient"
+        assert torch.equal(g1[n], g2[n]), f"{n}: not repeatable under DDP"

@@ -257,6 +257,30 @@ def test_colsum_patchify_embed():
     dt = ops.text_embed_bwd(ids, dx, 1000)
     ref = torch.zeros(1000, 512, device=DEV).index_add_(0, ids.view(-1), dx.float())
     assert relerr(dt, ref) < 1e-5
+    # heavy hitters (the padding id fills most of a real batch), more occurrences than one list batch, bit-stable
+    ids2 = torch.randint(0, 1000, (600, 32), device=DEV)
+    ids2[:, 12:] = 0
+    ids2[:, 0] = 999
+    dx2 = rnd(600 * 32, 512, seed=11)
+    dt2 = ops.text_embed_bwd(ids2, dx2, 1000)
+    ref2 = torch.zeros(1000, 512, device=DEV, dtype=torch.float64).index_add_(0, ids2.view(-1), dx2.double())
+    assert relerr(dt2, ref2.float()) < 1e-5
+    assert torch.equal(dt2, ops.text_embed_bwd(ids2, dx2, 1000))
+    # ids outside the table: no fault, zero row + position embedding, flag raised on the host check, no gradient
+    bad = ids.clone()
+    bad[0, 3], bad[2, 5] = 1000, -7
+    xb = ops.text_embed(bad, table, tpos)
+    good = bad.clamp(0, 999)
+    refb = table[good].half()
+    refb[0, 3], refb[2, 5] = 0, 0
+    assert torch.equal(xb, (refb + tpos[:32].half()).view(-1, 512))
+    with pytest.raises(IndexError):
+        ops.raise_on_device_errors()
+    ops.raise_on_device_errors()                     # the flag was cleared
+    dtb = ops.text_embed_bwd(bad, dx, 1000)
+    keep = ((bad >= 0) & (bad < 1000)).view(-1)
+    refd = torch.zeros(1000, 512, device=DEV).index_add_(0, good.view(-1)[keep], dx.float()[keep])
+    assert relerr(dtb, refd) < 1e-5
 
 
 # ----------------------------------------------------------------------------- attention
