@@ -204,6 +204,30 @@ def fx_enc_tiny(mclip, mmodel, mopt, mmetrics):
     _enc_fixture(mclip, mmodel, "enc_tiny_notemp", synth.TINY, 3, 2, 20, ("fp32",), use_temp=False)
 
 
+def fx_enc_rank(mclip, mmodel, mopt, mmetrics):
+    """A batch large enough for retrieval ranks to differ: 32 captions x 32 videos of 4 frames through the reference's
+    encoders, its similarity (modeling.py:207-229) and its eval score S_video + mean top-k frame logits
+    (main_task_retrieval.py:332-336), with the rank metrics of metrics.py:12-39."""
+    dims, B, Fr, L, k = synth.TINY, 32, 4, 32, 2
+    sd = synth.finetune_state(dims)
+    ids, mask, vid, vf, idx = synth.finetune_batch(B, Fr, L, dims.image_res, tag="enc_rank")
+    for mode in ("fp32", "aswritten"):
+        model, _ = build_reference_model(mclip, mmodel.BirdModel, dims, sd, mode, max_frames=Fr)
+        with torch.no_grad():
+            q = model.text_encoder(ids, mask)
+            v, u = model.visual_encoder(vid, vf)
+            sv = model.loose_similarity(q, v)
+            sf = model.loose_similarity(q, u)
+            fk = torch.topk(sf, k=k, dim=2)[0].mean(dim=2)
+        loss = model(ids, mask, vid, vf, idx, 1)
+        mt = mmetrics.compute_metrics((sv + fk).numpy())
+        mv = mmetrics.compute_metrics(sv.numpy())
+        save(f"enc_rank_{mode}", dims=json.dumps(dims.to_dict()), B=B, F=Fr, L=L, k=k, text_feat=q, video_emb=v, frame_output=u,
+             S_video=sv, S_frame_topk=fk, loss=loss,
+             metrics_score=np.array([mt["R1"], mt["R5"], mt["R10"], mt["MR"], mt["MeanR"]]),
+             metrics_video=np.array([mv["R1"], mv["R5"], mv["R10"], mv["MR"], mv["MeanR"]]))
+
+
 def fx_enc_tiny16(mclip, mmodel, mopt, mmetrics):
     _enc_fixture(mclip, mmodel, "enc_tiny16", synth.TINY16, 2, 3, 32, ("fp32", "aswritten"))
 
@@ -378,7 +402,7 @@ def fx_manifest(mclip, mmodel, mopt, mmetrics):
     print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
 
 
-FIXTURES = {"manifest": fx_manifest, "head": fx_head, "enc_tiny": fx_enc_tiny, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
+FIXTURES = {"manifest": fx_manifest, "head": fx_head, "enc_tiny": fx_enc_tiny, "enc_rank": fx_enc_rank, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
             "bertadam": fx_bertadam, "train_ft": fx_train_ft, "moco": fx_moco}
 
 

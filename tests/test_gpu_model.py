@@ -227,12 +227,69 @@ def test_model_vs_reference_golden(name, dims, use_temp):
         gn = float(P[n].grad.float().norm())
         if abs(gn - ref[n]) > 0.15 * ref[n] + 2e-4:
             bad.append((n, gn, float(ref[n])))
-    assert len(bad) <= max(1, len(names) // 50), f"{len(bad)} grad norms off: {bad[:8]}"
+    assert not bad, f"{len(bad)} of {len(names)} grad norms off: {bad[:8]}"
 
 
-@pytest.mark.parametrize("dims,name", [(synth.TINY, "enc_tiny")])
+def test_retrieval_ranks_b32_vs_reference():
+    """End-to-end acceptance on a batch where ranks CAN differ: 32 captions x 32 videos (4 frames) through the HIP towers,
+    the 32 x 32 video-text matrix and the eval score S_video + mean top-2 frame logits (main_task_retrieval.py:332-336)
+    against the reference's own outputs (tests/golden/enc_rank_*.npz).  The reference's two regimes (fp16 as written, fp32
+    upcast) already disagree with each other in 24 / 54 / 36 of the 1 024 argsort positions of these matrices (adjacent
+    logits are a median 0.03 apart, fp16 noise is 0.014), so "identical ranks" is asserted as: (1) every logit within the
+    fp16 envelope of the as-written reference, (2) every pair of candidates the reference separates by more than twice
+    that envelope in the same order (so every ground-truth rank equals the reference's unless a competitor is that close), (3) no more than twice as many argsort positions away from either regime of the reference
+    as its regimes are from each other, (4) the rank metrics of metrics.py equal up to those near ties."""
+    from hmmc_amd import metrics as M
+    ga, gf = golden("enc_rank_aswritten"), golden("enc_rank_fp32")
+    B, Fr, L, k = int(ga["B"]), int(ga["F"]), int(ga["L"]), int(ga["k"])
+    model, sd = build(synth.TINY, max_frames=Fr, top_frames=k)
+    ids, mask, vid, vf, idx = [t.to(DEV) for t in synth.finetune_batch(B, Fr, L, synth.TINY.image_res, tag="enc_rank")]
+    with torch.no_grad():
+        q = model.text_encoder(ids, mask)
+        v, u = model.visual_encoder(vid, vf)
+        sv, fk = model.eval_scores(q, v, u, top_frames=k)
+    sv, fk = sv.cpu().numpy(), fk.cpu().numpy()
+    # envelope: 1.5 x the largest difference between the reference's own two regimes on these logits (0.0143 -> 0.0215)
+    env = 1.5 * max(float(np.abs(ga[k_] - gf[k_]).max()) for k_ in ("S_video", "S_frame_topk"))
+    for mine, key in ((sv, "S_video"), (fk, "S_frame_topk"), (sv + fk, None)):
+        ra = ga[key] if key else ga["S_video"] + ga["S_frame_topk"]
+        rf = gf[key] if key else gf["S_video"] + gf["S_frame_topk"]
+        what = key or "score"
+        err = np.abs(mine - ra).max()
+        print(f"{what}: max |logit - reference| = {err:.4f} (envelope {env * (2 if key is None else 1):.4f})")
+        assert err <= env * (2 if key is None else 1), f"{what}: logits off by {err}"
+        gap = ra[:, :, None] - ra[:, None, :]
+        far = np.abs(gap) > 2 * env * (2 if key is None else 1)
+        mygap = mine[:, :, None] - mine[:, None, :]
+        assert (np.sign(mygap[far]) == np.sign(gap[far])).all(), f"{what}: a pair the reference separates clearly is out of order"
+        flips = int((np.argsort(-mine, 1) != np.argsort(-ra, 1)).sum())
+        own = int((np.argsort(-rf, 1) != np.argsort(-ra, 1)).sum())
+        # two independent fp16 evaluations differ by sqrt(2) x the noise of one fp16 evaluation against fp32: allow 2 x
+        assert flips <= 2 * own, f"{what}: {flips} argsort positions differ from the reference; its own regimes differ in {own}"
+        vs32 = int((np.argsort(-mine, 1) != np.argsort(-rf, 1)).sum())
+        assert vs32 <= 2 * own, f"{what}: {vs32} argsort positions differ from the reference's fp32 regime ({own} for its fp16 one)"
+    # rank of the ground-truth video per caption (metrics.py:20-28, computed on the device): equal to the reference's
+    # wherever no competitor sits within the envelope of the ground truth's own logit, and never further away than the
+    # number of such competitors; R@K / median / mean follow
+    for mine, key, width in ((sv + fk, "metrics_score", 2), (sv, "metrics_video", 1)):
+        ra = ga["S_video"] + ga["S_frame_topk"] if width == 2 else ga["S_video"]
+        ref_rank = (ra > np.diag(ra)[:, None]).sum(1)
+        amb = (np.abs(ra - np.diag(ra)[:, None]) <= 2 * env * width).sum(1) - 1
+        my_rank = M.ranks(torch.from_numpy(np.ascontiguousarray(mine)).to(DEV))
+        assert (np.abs(my_rank - ref_rank) <= amb).all(), (key, my_rank, ref_rank, amb)
+        assert (my_rank == ref_rank)[amb == 0].all()
+        mt = M.metrics_from_ranks(my_rank)
+        got = np.array([mt["R1"], mt["R5"], mt["R10"], mt["MR"], mt["MeanR"]])
+        moved = int((my_rank != ref_rank).sum())
+        assert np.abs(got[:3] - ga[key][:3]).max() <= 100.0 * moved / B + 1e-9, (key, got, ga[key])
+        assert abs(got[4] - ga[key][4]) <= float(np.abs(my_rank - ref_rank).sum()) / B + 1e-6, (key, got, ga[key])
+
+
+@pytest.mark.parametrize("dims,name", [(synth.TINY, "enc_tiny"), (synth.VIT_B32, "enc_b32")])
 def test_model_vs_oracle_fp32_gradients(dims, name):
-    """Direction check of every gradient against the fp32 oracle (cosine similarity)."""
+    """Direction check of every gradient against the fp32 oracle (cosine similarity): the tiny model, and the true
+    ViT-B/32 dimensions (12 layers, 12 heads, K = 3072: the shapes that take the 256x256 GEMM tile, split-K and the fused
+    bias-gradient partials in production)."""
     g = golden(f"{name}_fp32")
     B, Fr, L = int(g["B"]), int(g["F"]), int(g["L"])
     model, sd = build(dims)
