@@ -43,6 +43,10 @@ SIGNATURES = {
     "hmmc_infonce_bwd": ("pppppiiffp", "i"),
     "hmmc_retrieval_rank": ("pppiilip", "i"),
     "hmmc_topk_mean": ("pppiiiillp", "i"),
+    "hmmc_segment_max": ("pppiilp", "i"),
+    "hmmc_eval_slots": ("i", "i"),
+    "hmmc_eval_pack": ("pppiiip", "i"),
+    "hmmc_eval_score": ("pppppiiiiifp", "i"),
     "hmmc_temporal_pool_fwd": ("ppppiiip", "i"),
     "hmmc_temporal_pool_bwd": ("pppppiiip", "i"),
     "hmmc_add_rowbias": ("pppliip", "i"),

@@ -21,6 +21,8 @@ enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_RELU = 16 
 struct G32 {
   const float* A; const float* B; float* C; const float* bias; const float* resid; float* aux_out; const float* aux_in;
   int M, N, K; long sam, sak, sbk, sbn; int ldc; float alpha; int flags; int avec, bvec, cvec;
+  // eval scorer (TOPK kernels): B rows are videos x P slots (slot 0 = video embedding, 1..F = frames, rest zero padding)
+  int tk_F, tk_P, tk_k, tk_nv; float* tk_video; float* tk_frame; float* tk_score;
 };
 
 __device__ __forceinline__ float qgelu32(float h) { return h / (1.0f + __expf(-1.702f * h)); }
@@ -178,14 +180,72 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(G32 p) {
   }
 }
 
-template <int AMODE, int BMODE>
+// ---- eval scorer epilogue: video logit + mean of the top-k frame logits, straight from the accumulators -----------------
+// (main_task_retrieval.py:332-336: loose_similarity(query, visual), topk(loose_similarity(query, frames), k, dim=2).mean(2);
+// the [queries, videos, F] tensor of the reference is never written.)  The NV values of one (query, video) pair sit in
+// the 4 lanes with the same lane & 15: v[e] has slot slot0[e / 4] + 4 (lane >> 4) + (e & 3).  k rounds of: best
+// (value, lowest slot on ties, as torch.topk counts equal values separately) in the lane, two xor-shuffles (16, 32) across
+// the four lanes, the owner retires the winner.  Returns the video logit (slot 0) and the top-k mean, on all four lanes.
+template <int NV>
+__device__ __forceinline__ void topk_video(float (&v)[NV], int lane, int F, int k, float& s_video, float& s_frames) {
+  const int g = lane >> 4;
+  int slot[NV];
+#pragma unroll
+  for (int e = 0; e < NV; ++e) slot[e] = 16 * (e >> 2) + 4 * g + (e & 3);
+  float own0 = (g == 0) ? v[0] : 0.f;                                   // slot 0 lives in lane group 0
+  own0 += __shfl_xor(own0, 16, 64);
+  own0 += __shfl_xor(own0, 32, 64);
+  s_video = own0;
+#pragma unroll
+  for (int e = 0; e < NV; ++e)
+    if (slot[e] == 0 || slot[e] > F) v[e] = -INFINITY;
+  float sum = 0.f;
+  for (int t = 0; t < k; ++t) {
+    float bv = -INFINITY;
+    int bs = 1 << 20;
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+      if (v[e] > bv || (v[e] == bv && slot[e] < bs)) { bv = v[e]; bs = slot[e]; }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int os = __shfl_xor(bs, off, 64);
+      if (ov > bv || (ov == bv && os < bs)) { bv = ov; bs = os; }
+    }
+    sum += bv;
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+      if (slot[e] == bs) v[e] = -INFINITY;
+  }
+  s_frames = sum / (float)k;
+}
+
+__device__ __forceinline__ void topk_emit(const G32& p, int m, int video, int lane, float s_video, float s_frames) {
+  if ((lane >> 4) != 0 || m >= p.M || video >= p.tk_nv) return;
+  const long o = (long)m * p.tk_nv + video;
+  if (p.tk_video) p.tk_video[o] = s_video;
+  if (p.tk_frame) p.tk_frame[o] = s_frames;
+  if (p.tk_score) p.tk_score[o] = s_video + s_frames;
+}
+
+template <int AMODE, int BMODE, bool TOPK = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
   __shared__ __attribute__((aligned(16))) float sA[2][TK * LDS_LD];
   __shared__ __attribute__((aligned(16))) float sB[2][TK * LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int ntn = (p.N + TN - 1) / TN;
-  const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+  int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+  if constexpr (TOPK) {
+    // 15 000 x 48 000 outputs: walk the tiles in groups of 16 row tiles so that the ~256 workgroups resident together
+    // share 16 query tiles and 16 video tiles (4 MiB of operands in L2) instead of 1 and 256 (33 MiB)
+    constexpr int GROUP = 16;
+    const int ntm = (p.M + TM - 1) / TM;
+    const int grp = blockIdx.x / (GROUP * ntn), within = blockIdx.x % (GROUP * ntn);
+    const int gm = min(GROUP, ntm - grp * GROUP);
+    tm = grp * GROUP + within % gm;
+    tn = within / gm;
+  }
   const int m0 = tm * TM, n0 = tn * TN;
 
   f4 acc[2][2];
@@ -277,11 +337,59 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
     }
   }
   // lane owns C[m = .. + (lane & 15)][n = .. + 4*(lane >> 4) + r]
+  if constexpr (TOPK) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 32 + i * 16 + (lane & 15);
+      float sv, sf;
+      if (p.tk_P == 16) {                          // one video per 16-column MFMA tile
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+          topk_video<4>(v, lane, p.tk_F, p.tk_k, sv, sf);
+          topk_emit(p, m, (n0 + wn * 32 + j * 16) >> 4, lane, sv, sf);
+        }
+      } else {                                     // P == 32: the wave's two tiles are one video
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[i][e >> 2][e & 3] * p.alpha;
+        topk_video<8>(v, lane, p.tk_F, p.tk_k, sv, sf);
+        topk_emit(p, m, (n0 + wn * 32) >> 5, lane, sv, sf);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       store_tile16(p, acc[i][j], m0 + wm * 32 + i * 16 + (lane & 15), n0 + wn * 32 + j * 16 + 4 * (lane >> 4));
+}
+
+// packed[video * P + slot][:] = unit row: slot 0 = visual[video], 1..F = frames[video][slot - 1], slots past F zero
+// (loose_similarity normalises both sides without an epsilon, modules/modeling.py:211-213)
+__global__ __launch_bounds__(256) void eval_pack_kernel(const float* __restrict__ visual, const float* __restrict__ frames,
+                                                        float* __restrict__ packed, int nv, int F, int E, int P) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per packed row
+  if (row >= (long)nv * P) return;
+  const int video = (int)(row / P), slot = (int)(row % P);
+  float* dst = packed + row * E;
+  if (slot > F) {
+    for (int e = lane * 4; e < E; e += 256) *reinterpret_cast<f4*>(dst + e) = f4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const float* src = slot == 0 ? visual + (long)video * E : frames + ((long)video * F + slot - 1) * E;
+  float ss = 0.f;
+  for (int e = lane * 4; e < E; e += 256) {
+    const f4 x = *reinterpret_cast<const f4*>(src + e);
+    ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+  }
+  const float inv = 1.0f / sqrtf(wave_sum(ss));
+  for (int e = lane * 4; e < E; e += 256) {
+    const f4 x = *reinterpret_cast<const f4*>(src + e);
+    *reinterpret_cast<f4*>(dst + e) = f4{x[0] * inv, x[1] * inv, x[2] * inv, x[3] * inv};
+  }
 }
 
 template <int AMODE>
@@ -343,5 +451,34 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
     case OP_RVEC: launch_f32<OP_RVEC>(bmode, grid, stream, p); break;
     default: launch_f32<OP_SCALAR>(bmode, grid, stream, p); break;
   }
+  return hmmc_launch_status();
+}
+
+// ---- eval scorer (reference main_task_retrieval.py:321-357 _run_on_single_gpu, modules/modeling.py:207-229) -----------------
+extern "C" int hmmc_eval_slots(int F) { return F + 1 <= 16 ? 16 : F + 1 <= 32 ? 32 : 0; }
+
+extern "C" int hmmc_eval_pack(const float* visual, const float* frames, float* packed, int nv, int F, int E,
+                              hipStream_t stream) {
+  const int P = hmmc_eval_slots(F);
+  if (!visual || !frames || !packed || nv <= 0 || F <= 0) return HMMC_ERR_ARG;
+  if (!P || (E & 3) || (((uintptr_t)visual | (uintptr_t)frames | (uintptr_t)packed) & 15)) return HMMC_ERR_UNSUPPORTED;
+  const long rows = (long)nv * P;
+  hipLaunchKernelGGL(eval_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, visual, frames, packed, nv, F, E, P);
+  return hmmc_launch_status();
+}
+
+extern "C" int hmmc_eval_score(const float* queries_unit, const float* packed, float* out_video, float* out_frame,
+                               float* out_score, int nq, int nv, int F, int E, int k, float scale, hipStream_t stream) {
+  const int P = hmmc_eval_slots(F);
+  if (!queries_unit || !packed || nq <= 0 || nv <= 0 || F <= 0 || k <= 0 || k > F) return HMMC_ERR_ARG;
+  if (!out_video && !out_frame && !out_score) return HMMC_ERR_ARG;
+  if (!P || (E & 3) || (((uintptr_t)queries_unit | (uintptr_t)packed) & 15) || (long)nv * P >= (1l << 31)) return HMMC_ERR_UNSUPPORTED;
+  G32 p{};
+  p.A = queries_unit; p.B = packed; p.C = nullptr;
+  p.M = nq; p.N = nv * P; p.K = E; p.sam = E; p.sak = 1; p.sbk = 1; p.sbn = E; p.ldc = 0; p.alpha = scale; p.flags = 0;
+  p.avec = p.bvec = 1; p.cvec = 0;
+  p.tk_F = F; p.tk_P = P; p.tk_k = k; p.tk_nv = nv; p.tk_video = out_video; p.tk_frame = out_frame; p.tk_score = out_score;
+  const long blocks = (long)((nq + TM - 1) / TM) * ((p.N + TN - 1) / TN);
+  hipLaunchKernelGGL((gemm_f32_kernel<OP_KVEC, OP_KVEC, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
   return hmmc_launch_status();
 }

@@ -360,6 +360,27 @@ __global__ __launch_bounds__(256) void retrieval_rank_kernel(const float* __rest
   if (lane == 0) rank[q] = (int)cnt;
 }
 
+// out[g][v] = max over the sentences s of group g (offsets[g] <= s < offsets[g + 1]) of S[s][v]: the video-to-text matrix of
+// multi-sentence retrieval (metrics.py:79-86 tensor_video_to_text_sim: max over a video's captions; NaN counts as -inf),
+// stored [groups][videos] so that hmmc_retrieval_rank(transposed = 1) ranks it without a transposed copy.
+__global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ S, const int* __restrict__ offsets,
+                                                          float* __restrict__ out, int G, int V, long ld) {
+  const int g = blockIdx.y;
+  const int s0 = offsets[g], s1 = offsets[g + 1];
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x) {
+    float m = -INFINITY;
+    for (int s = s0; s < s1; ++s) m = fmaxf(m, S[(long)s * ld + v]);
+    out[(long)g * V + v] = m;
+  }
+}
+
+extern "C" int hmmc_segment_max(const float* S, const int* offsets, float* out, int groups, int V, long ld, hipStream_t stream) {
+  if (!S || !offsets || !out || groups <= 0 || V <= 0 || ld < V) return HMMC_ERR_ARG;
+  if (groups > 65535) return HMMC_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(segment_max_kernel, dim3((V + 255) / 256, groups), dim3(256), 0, stream, S, offsets, out, groups, V, ld);
+  return hmmc_launch_status();
+}
+
 extern "C" int hmmc_topk_mean(const float* S_frame, const float* base, float* out, int bq, int bv, int F, int k, long lds,
                               long ldb, hipStream_t stream) {
   if (!S_frame || !out || bq <= 0 || bv <= 0 || F <= 0 || F > 64 || k <= 0 || k > F) return HMMC_ERR_ARG;

@@ -373,13 +373,53 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
         S = ops.gemm_f32(qn, vn, qn.shape[0], vn.shape[0], E, (E, 1), (1, E), alpha=scale)
         return S.view(qn.shape[0], v.shape[0], v.shape[1]) if three_d else S
 
-    def eval_scores(self, query_output, visual_output, frame_output, top_frames=None):
-        """video-text logits + mean of the top-k frame-text logits (main_task_retrieval.py:332-336,512-513)."""
+    def eval_scores(self, query_output, visual_output, frame_output, top_frames=None, packed=None):
+        """(video-text logits, mean of the top-k frame-text logits), each [queries, videos]
+        (main_task_retrieval.py:332-336: loose_similarity twice, torch.topk(frame_logits, k, dim=2)[0].mean(2)).
+        One fused launch (hmmc_eval_score): the [queries, videos, F] logits tensor the reference materialises - 2.16 GB at
+        VATEX's 15 000 x 1 500 x 24 - is never written.  `packed` = ops.eval_pack(visual, frames) of the candidates, for
+        callers that score many query batches against the same videos."""
         k = top_frames or self.top_frames
-        sv = self.loose_similarity(query_output, visual_output)
-        sf = self.loose_similarity(query_output, frame_output)
-        bq, bv, F = sf.shape
-        return sv, ops.topk_mean(sf.view(bq, bv * F), bq, bv, F, k)
+        q = query_output.contiguous().float().view(-1, query_output.shape[-1])
+        v = visual_output.contiguous().float().view(-1, q.shape[-1])
+        u = frame_output.contiguous().float()
+        nv, F, E = u.shape
+        scale = min(math.exp(float(self.text_encoder.logit_scale)), 100.0)
+        if ops.eval_slots(F) == 0:                       # more than 31 frames per video: two launches, [bq, bv, F] in HBM
+            sv = self.loose_similarity(q, v)
+            sf = self.loose_similarity(q, u)
+            return sv, ops.topk_mean(sf.view(q.shape[0], nv * F), q.shape[0], nv, F, k)
+        qn, _ = ops.l2norm_fwd(q)
+        if packed is None:
+            packed = ops.eval_pack(v, u)
+        sv, sf, _ = ops.eval_score(qn, packed, nv, F, k, scale)
+        return sv, sf
+
+    @torch.no_grad()
+    def eval_similarity(self, batch_query_output_list, batch_visual_output_list, batch_frame_output_list,
+                        use_frame_fea=True, query_chunk=4096):
+        """The cached-feature scoring loop of eval_epoch (main_task_retrieval.py:321-357 _run_on_single_gpu + :512-513):
+        lists of per-batch query / video / frame features -> the [all queries, all videos] score matrix
+        sim_matrix (+ sim_matrix_frame when use_frame_fea), on the device.  The reference runs len(queries) x len(videos)
+        small matmuls with a host copy each; here the candidates are packed once and every chunk of queries is one launch."""
+        q = torch.cat([t.float() for t in batch_query_output_list], dim=0)
+        v = torch.cat([t.float() for t in batch_visual_output_list], dim=0)
+        u = torch.cat([t.float() for t in batch_frame_output_list], dim=0)
+        nv, F, E = u.shape
+        k = self.top_frames
+        if ops.eval_slots(F) == 0:
+            sv, sf = self.eval_scores(q, v, u)
+            return sv + sf if use_frame_fea else sv
+        scale = min(math.exp(float(self.text_encoder.logit_scale)), 100.0)
+        packed = ops.eval_pack(v.contiguous(), u.contiguous())
+        qn, _ = ops.l2norm_fwd(q.contiguous())
+        out = torch.empty((q.shape[0], nv), dtype=torch.float32, device=q.device)
+        for s in range(0, q.shape[0], query_chunk):
+            e = min(q.shape[0], s + query_chunk)
+            want = ("score",) if use_frame_fea else ("video",)
+            sv, sf, sc = ops.eval_score(qn[s:e], packed, nv, F, k, scale, want=want)
+            out[s:e] = sc if use_frame_fea else sv
+        return out
 
 
 class BirdModel(BirdPreTrainedModel):

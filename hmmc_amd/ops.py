@@ -363,6 +363,42 @@ def topk_mean(S_frame, bq, bv, F, k, base=None, lds=None, ldb=None):
     return out
 
 
+def eval_slots(F):
+    """rows per video of the packed candidate matrix of the fused eval scorer (0: too many frames for it)."""
+    return query("hmmc_eval_slots", int(F))
+
+
+def eval_pack(visual, frames):
+    """[nv, E], [nv, F, E] -> unit rows [nv * slots, E] (slot 0 video embedding, 1..F frames, rest zero)."""
+    _chk(visual, torch.float32, "visual")
+    _chk(frames, torch.float32, "frames")
+    nv, F, E = frames.shape
+    P = eval_slots(F)
+    packed = torch.empty((nv * P, E), dtype=torch.float32, device=visual.device)
+    call("hmmc_eval_pack", ptr(visual.contiguous()), ptr(frames.contiguous()), ptr(packed), nv, F, E)
+    return packed
+
+
+def eval_score(queries_unit, packed, nv, F, k, scale, want=("video", "frame")):
+    """fused scale * Q [V; U]^T -> (video logits, mean top-k frame logits, their sum), each [nq, nv] or None."""
+    _chk(queries_unit, torch.float32, "queries_unit")
+    nq, E = queries_unit.shape
+    outs = [torch.empty((nq, nv), dtype=torch.float32, device=packed.device) if w in want else None
+            for w in ("video", "frame", "score")]
+    call("hmmc_eval_score", ptr(queries_unit), ptr(packed), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), nq, nv, F, E, int(k), float(scale))
+    return outs
+
+
+def segment_max(sim, offsets):
+    """out[g][v] = max over rows offsets[g] <= s < offsets[g+1] of sim[s][v]; offsets int32 [G + 1] on the device."""
+    _chk(sim, torch.float32, "sim")
+    _chk(offsets, torch.int32, "offsets")
+    G, V = offsets.numel() - 1, sim.shape[1]
+    out = torch.empty((G, V), dtype=torch.float32, device=sim.device)
+    call("hmmc_segment_max", ptr(sim), ptr(offsets), ptr(out), G, V, sim.stride(0))
+    return out
+
+
 def retrieval_rank(sim, target=None, transposed=False):
     """rank[q] = #{j : S(q, j) > S(q, target[q])} (int32); S(q, j) = sim[q, j], or sim[j, q] with transposed."""
     _chk(sim, torch.float32, "sim")

@@ -148,6 +148,21 @@ int hmmc_topk_mean(const float* S_frame, const float* base, float* out, int bq, 
  * rank follow from the Q integers on the host, as in the reference. */
 int hmmc_retrieval_rank(const float* S, const int* target, int* rank, int Q, int V, long ld, int transposed,
                         hmmc_stream_t stream);
+/* Video-to-text matrix of multi-sentence retrieval (metrics.py:79-86 tensor_video_to_text_sim): out[g][v] = max over the
+ * sentences offsets[g] <= s < offsets[g+1] of S[s][v] (NaN counts as -inf); offsets is a device int32 [groups + 1].
+ * Rank it with hmmc_retrieval_rank(transposed = 1). */
+int hmmc_segment_max(const float* S, const int* offsets, float* out, int groups, int V, long ld, hmmc_stream_t stream);
+/* Eval scorer (main_task_retrieval.py:321-357 _run_on_single_gpu; modules/modeling.py:207-229 loose_similarity):
+ * hmmc_eval_slots(F) = rows per video of the packed candidate matrix (16 or 32; 0: F + 1 > 32, use hmmc_gemm_f32 +
+ * hmmc_topk_mean).  hmmc_eval_pack writes packed [nv * slots][E]: slot 0 = visual[v] / |visual[v]|, slots 1..F =
+ * frames[v][f] / |frames[v][f]|, the rest zero.  hmmc_eval_score computes, for every (query, video), the video logit
+ * scale * q . v and the mean of the k largest frame logits scale * q . u_f in ONE pass (exact-f32 MFMA, top-k by wave
+ * shuffles on the accumulators): the [queries, videos, F] tensor of the reference is never written.  Outputs are
+ * [nq][nv] fp32; any of the three may be NULL (out_score = out_video + out_frame).  queries_unit rows have unit norm. */
+int hmmc_eval_slots(int F);
+int hmmc_eval_pack(const float* visual, const float* frames, float* packed, int nv, int F, int E, hmmc_stream_t stream);
+int hmmc_eval_score(const float* queries_unit, const float* packed, float* out_video, float* out_frame, float* out_score,
+                    int nq, int nv, int F, int E, int k, float scale, hmmc_stream_t stream);
 
 /* video_emb[b] = mean_f (h + u)/||h + u||  (modules/module_cross.py:207-212); u may be NULL (use_temp False). */
 int hmmc_temporal_pool_fwd(const float* h, const float* u, float* out, float* norms, int b, int F, int D,

@@ -228,6 +228,40 @@ def fx_enc_rank(mclip, mmodel, mopt, mmetrics):
              metrics_video=np.array([mv["R1"], mv["R5"], mv["R10"], mv["MR"], mv["MeanR"]]))
 
 
+def fx_multisent(mclip, mmodel, mopt, mmetrics):
+    """Multi-sentence retrieval metrics (MSVD / VATEX style: several captions per video) through the reference's own
+    logging_rank (metrics.py:89-144): uneven caption counts; case t repeats case a with exact ties planted in one row."""
+    import logging
+    out = {}
+    for tag, counts, seed in (("a", [3, 1, 9, 2, 5, 1, 4, 7, 2, 6, 1, 8], 7), ("b", [10] * 30, 11), ("c", [1, 2, 3, 4, 20, 1, 1, 6], 13),
+                              ("t", [3, 1, 9, 2, 5, 1, 4, 7, 2, 6, 1, 8], 7)):
+        n_video, n_sent = len(counts), sum(counts)
+        rng = np.random.Generator(np.random.Philox(key=seed))
+        sim = rng.normal(size=(n_sent, n_video)).astype(np.float32) * 3.0
+        vid = np.repeat(np.arange(n_video), counts)
+        sim[np.arange(n_sent), vid] += 2.0                       # the right video tends to win
+        if tag == "t":
+            sim[5, :] = np.round(sim[5, :])                      # exact ties in one row: the reference's rank is then whatever
+                                                                 # position torch.argsort (unstable) gives the ground truth
+        cut = list(np.cumsum(counts) - 1)                        # eval_epoch's cut_off_points_ (index of a video's last sentence)
+        captured = {}
+        orig = mmetrics.compute_metrics
+
+        def spy(x, _orig=orig, _c=captured):
+            _c["vt"] = _orig(x)
+            return _c["vt"]
+        mmetrics.compute_metrics = spy
+        try:
+            tv = mmetrics.logging_rank(sim.copy(), True, cut, logging.getLogger("golden"))
+        finally:
+            mmetrics.compute_metrics = orig
+        vt = captured["vt"]
+        out[f"{tag}.sim"], out[f"{tag}.cut"] = sim, np.asarray(cut)
+        out[f"{tag}.tv"] = np.array([tv["R1"], tv["R5"], tv["R10"], tv["MedianR"], tv["MeanR"], tv["Std_Rank"]])
+        out[f"{tag}.vt"] = np.array([vt["R1"], vt["R5"], vt["R10"], vt["MR"], vt["MeanR"]])
+    save("multisent", **out)
+
+
 def fx_enc_tiny16(mclip, mmodel, mopt, mmetrics):
     _enc_fixture(mclip, mmodel, "enc_tiny16", synth.TINY16, 2, 3, 32, ("fp32", "aswritten"))
 
@@ -402,7 +436,7 @@ def fx_manifest(mclip, mmodel, mopt, mmetrics):
     print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
 
 
-FIXTURES = {"manifest": fx_manifest, "head": fx_head, "enc_tiny": fx_enc_tiny, "enc_rank": fx_enc_rank, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
+FIXTURES = {"manifest": fx_manifest, "head": fx_head, "enc_tiny": fx_enc_tiny, "enc_rank": fx_enc_rank, "multisent": fx_multisent, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
             "bertadam": fx_bertadam, "train_ft": fx_train_ft, "moco": fx_moco}
 
 
