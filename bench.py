@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""HMMC hot-path benchmark: video-text pairs / second of one fine-tuning step
-(forward + backward + global grad clip + BertAdam step, reference main_task_retrieval.py:272-302)
-on synthetic MSR-VTT-shaped batches [B=256, F=12, 3x224x224], ViT-B/32 + CLIP text transformer.
+"""HMMC hot-path benchmark: video-text pairs / second of one training step
+(forward + backward + global grad clip + BertAdam step, reference main_task_retrieval.py:272-302 /
+main_pretrain.py:213-245) on synthetic batches.  Default = BASELINE.json's headline config: MSR-VTT-shaped fine-tuning
+[B=256, F=12, 3x224x224], ViT-B/32 + CLIP text transformer.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --mode pretrain --batch 128                       # SURVEY config 4 (FAM+VTM+FTM+MLM, MoCo K=1024)
+    python bench.py --clip ViT-B/16 --frames 24 --batch 16            # one rank's share of SURVEY config 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -23,11 +26,27 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_PAIR_TRAIN = 324.33e9      # ViT-B/32, F=12, L_text=32, the reference's formulation
-# what this implementation executes: the last ViT block's out_proj + MLP run on the class token only (49 of 50 tokens pruned,
-# 3 x 12 frames x (0.0590 + 0.4719) GFLOP x 49/50), see hmmc_tower_fwd's lead_only
-FLOP_PER_PAIR_EXECUTED = FLOP_PER_PAIR_TRAIN - 3 * 12 * (0.0590e9 + 0.4719e9) * 49 / 50
 MFMA_PEAK_TFLOPS = 2500.0           # dense fp16/bf16, MI355X_MICROARCH.md
+
+
+def flop_model(dims, frames, text_len):
+    """Algorithmic FLOPs (2 x MAC of GEMM-shaped work, the reference's formulation incl. its all-token final projection),
+    SURVEY.md section 8(d): ViT-B/32, F=12, L=32 -> 8.856 GFLOP per frame, 324.33 GFLOP per pair per fine-tune step."""
+    def tower(L, D, layers):
+        return layers * (2 * L * D * 3 * D + 4 * L * L * D + 2 * L * D * D + 16 * L * D * D)
+    g = dims.image_res // dims.patch
+    Lv, D, E = g * g + 1, dims.vision_width, 512
+    patch = 2 * (Lv - 1) * 3 * dims.patch * dims.patch * D
+    frame = patch + tower(Lv, D, dims.vision_layers) + 2 * Lv * D * E
+    text = tower(text_len, dims.text_width, dims.text_layers) + 2 * text_len * dims.text_width * E
+    temporal = tower(frames, E, 4)
+    fwd = frames * frame + text + temporal
+    lead = 3 * frames * (2 * Lv * D * D + 16 * Lv * D * D) * (Lv - 1) / Lv    # pruned: last block's out_proj + MLP off the class token
+    return {"frame_fwd": frame, "pair_fwd": fwd, "pair_train": 3 * fwd - frames * patch,
+            "pair_train_executed": 3 * fwd - frames * patch - lead}
+
+
+FLOP_PER_PAIR_PRETRAIN_C4 = 457.35e9     # SURVEY.md section 8(d), config 4: B=128, F=12, title 45 / tag 25, K=1024
 
 
 def task_config(**kw):
@@ -58,13 +77,26 @@ def prep_optimizer(model, cfg, t_total):
                     t_total=t_total, weight_decay=wd, max_grad_norm=1.0)
 
 
-def cpu_baseline(frames, length, seconds=20.0):
-    """The oracle's fp32 restatement of the same step, timed on this host's cores (rank 0, N=1 only)."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(frames, length, batch=16, warmups=2, min_steps=2, seconds=45.0):
+    """The oracle's fp32 restatement of the same fine-tune step, timed on this host's cores (rank 0, N=1 only).
+    BASELINE.md section 4: batch large enough for a step of 10-60 s (CPU pairs/s is flat in B past B ~ 8), >= 2 warm-up
+    steps, CPU model and core count reported."""
     from hmmc_amd import synth
     from oracle import hmmc_oracle as O
     cores = max(1, min(len(os.sched_getaffinity(0)), 64))     # the cores this process may actually use
     torch.set_num_threads(cores)
-    B = 4
+    B = batch
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in synth.finetune_state(synth.VIT_B32).items()}
     params = [v for v in sd.values() if v.requires_grad]
     state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items() if v.requires_grad}
@@ -83,32 +115,47 @@ def cpu_baseline(frames, length, seconds=20.0):
                     np_, m, v, _ = O.bert_adam_step(p.data, p.grad, m, v, i, 1e-4, 1000, 0.1, 0.2)
                     p.data.copy_(np_)
                     state[k] = (m, v)
-    print(f"[bench] cpu_baseline: oracle step on {cores} host threads ...", file=sys.stderr, flush=True)
-    step(0)                      # warm-up
-    print("[bench] cpu_baseline: warm-up step done", file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline: oracle step, B={B}, on {cores} host threads ...", file=sys.stderr, flush=True)
+    for w in range(warmups):
+        t0 = time.time()
+        step(w)
+        print(f"[bench] cpu_baseline: warm-up step {w + 1} took {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
     t0 = time.time()
     n = 0
-    while n < 2 or (time.time() - t0 < seconds and n < 8):
-        step(n + 1)
+    while n < min_steps or (time.time() - t0 < seconds and n < 5):
+        step(warmups + n)
         n += 1
         print(f"[bench] cpu_baseline: step {n} at {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
     dt = (time.time() - t0) / n
     return {"value": round(B / dt, 4), "unit": "video-text pairs/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 restatement, B={B} F={frames} L={length} ViT-B/32, {n} steps of {dt:.2f} s "
-                      f"(fwd+bwd+clip+BertAdam), torch CPU {torch.__version__}"}
+            "sample": f"oracle fp32 restatement of the fine-tune step, B={B} F={frames} L={length} ViT-B/32, {warmups} warm-up + {n} "
+                      f"timed steps of {dt:.2f} s (fwd+bwd+clip+BertAdam), {cores} threads of {_cpu_model()}, torch CPU {torch.__version__}"}
 
 
-def recorded_traffic(args, per_gpu_batch):
-    """HBM bytes per gemm_f16_kernel launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB units,
-    separate rocprofv3 --pmc runs of this same command; profiles/r01_gemm_f16_hbm_traffic.json).  The counters cannot
-    be read from inside the process, so the figure is only reported for the workload it was collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_gemm_f16_hbm_traffic.json")
-    if not (per_gpu_batch == 256 and args.frames == 12 and args.length == 32 and args.clip == "ViT-B/32"
-            and os.path.exists(path)):
-        return None
+def _gemm_source_hash():
+    import hashlib
+    with open(os.path.join(ROOT, "hmmc_amd", "csrc", "gemm_f16.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def recorded_traffic(args, per_gpu_batch, launches_per_step):
+    """HBM bytes per gemm_f16_kernel launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
+    rocprofv3 --pmc runs of this same command, scratch/pmc_traffic.py).  The counters cannot be read from inside the
+    process, so the figure is reported only for the workload AND the kernel source it was collected on: the record carries
+    the hash of gemm_f16.hip and the launches per step, and a mismatch reports the traffic as stale (None)."""
+    if not (args.mode == "finetune" and per_gpu_batch == 256 and args.frames == 12 and args.length == 32 and args.clip == "ViT-B/32"):
+        return None, "not collected for this workload"
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_f16_hbm_traffic.json")))
+    if not paths:
+        return None, "no PMC record"
+    path = paths[-1]
     with open(path) as f:
         rec = json.load(f)
-    return round(rec["hbm_traffic_per_launch_bytes"]), "profiles/r01_gemm_f16_hbm_traffic.json (rocprofv3 --pmc, separate passes)"
+    rel = os.path.relpath(path, ROOT)
+    if rec.get("gemm_f16_hip_sha256_16") != _gemm_source_hash() or rec.get("launches_per_step") != launches_per_step:
+        return None, f"{rel} is stale (collected on another gemm_f16.hip / launch count); re-run scratch/pmc_traffic.py"
+    return round(rec["hbm_traffic_per_launch_bytes"]), f"{rel} (rocprofv3 --pmc, separate passes)"
 
 
 def main():
@@ -116,9 +163,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="global batch (reference --batch_size)")
+    ap.add_argument("--mode", choices=("finetune", "pretrain"), default="finetune",
+                    help="finetune: BirdModel (configs 2/3/5); pretrain: BirdPreTrainedModel, FAM+VTM+FTM+MLM, MoCo queues (config 4)")
+    ap.add_argument("--batch", type=int, default=None, help="global batch (reference --batch_size); default 256 / 128 (pretrain)")
     ap.add_argument("--frames", type=int, default=12)
-    ap.add_argument("--length", type=int, default=32)
+    ap.add_argument("--length", type=int, default=32, help="caption length (fine-tune)")
+    ap.add_argument("--title-length", type=int, default=45)
+    ap.add_argument("--tag-length", type=int, default=25)
+    ap.add_argument("--negatives", type=int, default=1024, help="MoCo queue length K (pretrain)")
     ap.add_argument("--clip", default="ViT-B/32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
@@ -129,7 +181,10 @@ def main():
                          "giving it with --gpus 1 measures what the reservation costs")
     ap.add_argument("--roofline-steps", type=int, default=3,
                     help="extra single-stream steps after the timed region over which the GEMM launches are timed with HIP events")
+    ap.add_argument("--vit-forward-iters", type=int, default=5, help="timed frame-encoder forward passes for the vit_forward record (0: skip)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 256 if args.mode == "finetune" else 128
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -147,7 +202,7 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     from hmmc_amd import ops, synth
-    from hmmc_amd.modeling import BirdModel
+    from hmmc_amd.modeling import BirdModel, BirdPreTrainedModel
     from hmmc_amd.optimization import clip_grad_norm_
 
     if args.reserve_cus is not None:
@@ -159,26 +214,37 @@ def main():
         _md0._OVERLAP_TOWERS, _fn0._WGRAD_STREAM = False, False
     assert args.batch % world == 0
     b = args.batch // world
-    cfg = task_config(local_rank=local_rank, rank=rank, max_frames=args.frames, pretrained_clip_name=args.clip)
+    dims = synth.NAMED[args.clip]
+    pretrain = args.mode == "pretrain"
+    extra = dict(dataset="chvtt", contrast_momentum=0.99, contrast_temperature=0.07, contrast_num_negative=args.negatives,
+                 pretrained_text=None) if pretrain else {}
+    cfg = task_config(local_rank=local_rank, rank=rank, max_frames=args.frames, pretrained_clip_name=args.clip, **extra)
     torch.manual_seed(42)
-    model = BirdModel.from_pretrained("cross-base", state_dict=None, task_config=cfg).to(dev).train()
+    cls = BirdPreTrainedModel if pretrain else BirdModel
+    model = cls.from_pretrained("cross-base", state_dict=None, task_config=cfg).to(dev).train()
     optimizer = prep_optimizer(model, cfg, t_total=1000)
     net = model
     if world > 1:
+        # the pre-training model builds t_projector and never uses it (reference main_pretrain.py:204: find_unused_parameters)
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_dev], output_device=local_dev,
-                                                        find_unused_parameters=False, gradient_as_bucket_view=True)
+                                                        find_unused_parameters=pretrain, gradient_as_bucket_view=True)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    res = synth.NAMED[args.clip].image_res
+    res = dims.image_res
     video = torch.randn((b, args.frames, 3, res, res), generator=g, device=dev)
-    ids, mask = synth.token_ids(f"bench.ids.{rank}", b, args.length)
-    ids, mask = ids.to(dev), mask.to(dev)
     vf = torch.full((b,), args.frames, dtype=torch.long, device=dev)
-    idx = torch.arange(b, device=dev)
+    if pretrain:
+        title, tmask = [t.to(dev) for t in synth.token_ids(f"bench.title.{rank}", b, args.title_length)]
+        tag, gmask = [t.to(dev) for t in synth.token_ids(f"bench.tag.{rank}", b, args.tag_length)]
+        inputs = (video, vf, tag, gmask, title, tmask)
+    else:
+        ids, mask = [t.to(dev) for t in synth.token_ids(f"bench.ids.{rank}", b, args.length)]
+        inputs = (ids, mask, video, vf, torch.arange(b, device=dev))
+    params = [p for p in model.parameters() if p.requires_grad]
 
     def step(i):
-        loss = net(ids, mask, video, vf, idx, i)
+        loss = net(*inputs, i)
         loss.backward()
-        clip_grad_norm_(model.parameters(), 1.0)
+        clip_grad_norm_(params, 1.0)
         optimizer.step()
         optimizer.zero_grad()
         return loss
@@ -201,6 +267,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     final_loss = float(loss.detach())
+    ops.raise_on_device_errors()
 
     # Roofline of the dominant kernel.  The timed region above runs the text tower, the frame tower and the weight
     # gradients on three streams, so a launch's HIP events there also bracket the time it waits for CUs held by another
@@ -222,6 +289,28 @@ def main():
     prof = ops.gemm_profile_stop()
     _md._OVERLAP_TOWERS, _fn._WGRAD_STREAM = ov
 
+    # ViT forward alone (north_star: MFMA utilisation of the ViT forward): the frame encoder over this rank's b x F frames in
+    # eval mode, timed with events on the current stream; FLOPs in the reference's formulation (all-token final projection)
+    fm = flop_model(dims, args.frames, args.length)
+    vit_forward = None
+    if args.vit_forward_iters > 0:
+        frames_flat = video.view(b * args.frames, 3, res, res)
+        enc = model.visual_encoder
+        with torch.no_grad():
+            enc.encode_image(frames_flat)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.vit_forward_iters):
+                enc.encode_image(frames_flat)
+            e1.record()
+            torch.cuda.synchronize()
+        vms = e0.elapsed_time(e1) / args.vit_forward_iters
+        vtf = b * args.frames * fm["frame_fwd"] / (vms * 1e-3) / 1e12
+        vit_forward = {"ms": round(vms, 3), "frames": b * args.frames, "tflops_reference_formulation": round(vtf, 1),
+                       "frac_of_mfma_peak": round(vtf / MFMA_PEAK_TFLOPS, 4),
+                       "note": "frame encoder forward (patch embed + blocks + ln_post/proj) of one rank's frames, no_grad"}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = args.batch * args.steps / dt
@@ -229,37 +318,45 @@ def main():
         secs = sum(p["seconds"] for p in prof.values())
         launches = sum(p["launches"] for p in prof.values())
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
+        lps = launches // max(args.roofline_steps, 1)
         roof = {"bound": "mfma", "kernel": "gemm_f16_kernel (fp16 MFMA GEMM, all operand layouts)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None, "traffic_unit": "bytes/launch",
-                "launches_per_step": launches // max(args.roofline_steps, 1),
+                "launches_per_step": lps,
                 "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),
                 "measured_over": f"{args.roofline_steps} single-stream steps after the timed region "
                                  f"({dt_single / max(args.roofline_steps, 1) * 1e3:.2f} ms/step without the stream overlap)",
                 "gemm_share_of_step": round(secs / dt_single, 4),
+                "algorithmic_bytes_per_launch": round(sum(p.get("bytes", 0) for p in prof.values()) / max(launches, 1)) or None,
                 "by_layout": {k: {"tflops": round(p["flops"] / p["seconds"] / 1e12, 1), "launches": p["launches"],
                                   "avg_us": round(p["seconds"] / p["launches"] * 1e6, 2)} for k, p in prof.items()}}
-        rec = recorded_traffic(args, b)
-        if rec is not None:
-            roof["traffic"], roof["traffic_source"] = rec
-            roof["algorithmic_bytes_per_launch"] = round(sum(p.get("bytes", 0) for p in prof.values()) / max(launches, 1)) or None
-        out = {"metric": "video-text pairs/sec (whole node), B=256 F=12 224^2", "value": round(value, 2),
+        roof["traffic"], roof["traffic_source"] = recorded_traffic(args, b, lps)
+        if pretrain:
+            c4 = (args.clip == "ViT-B/32" and args.frames == 12 and args.title_length == 45 and args.tag_length == 25)
+            per_pair, per_pair_exec = (FLOP_PER_PAIR_PRETRAIN_C4 if c4 else None), None
+            workload = (f"{args.clip} CHVTT-shaped pre-train step (FAM+VTM+FTM+MLM, MoCo m=0.99 K={args.negatives}), global B={args.batch} "
+                        f"F={args.frames} title L={args.title_length} tag L={args.tag_length}, {res}x{res}, fwd+bwd+clip+BertAdam, random-init weights")
+        else:
+            per_pair, per_pair_exec = fm["pair_train"], fm["pair_train_executed"]
+            workload = (f"{args.clip} english fine-tune step, global B={args.batch} F={args.frames} L_text={args.length}, "
+                        f"{res}x{res}, fwd+bwd+clip+BertAdam, random-init weights")
+        headline = (not pretrain and args.batch == 256 and args.frames == 12 and args.clip == "ViT-B/32" and res == 224)
+        metric = ("video-text pairs/sec (whole node), B=256 F=12 224^2" if headline else
+                  f"video-text pairs/sec (whole node), {args.mode} {args.clip} B={args.batch} F={args.frames} {res}^2")
+        out = {"metric": metric, "value": round(value, 2),
                "unit": "video-text pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f16", "data": "synthetic",
-               "config": {"workload": f"{args.clip} english MSR-VTT fine-tune step, global B={args.batch} F={args.frames} "
-                                      f"L_text={args.length}, 224x224, fwd+bwd+clip+BertAdam, random-init weights",
-                          "global_batch": args.batch, "per_gpu_batch": b, "frames": args.frames,
+               "config": {"workload": workload, "mode": args.mode, "global_batch": args.batch, "per_gpu_batch": b, "frames": args.frames,
                           "parallelism": f"dp{world}", "streams": "single" if args.single_stream else "overlapped",
                           "gemm_reserved_cus": reserved},
-               "step_tflops": round(value * FLOP_PER_PAIR_EXECUTED / 1e12, 1) if args.clip == "ViT-B/32" and args.frames == 12 else None,
-               "step_tflops_reference_formulation": round(value * FLOP_PER_PAIR_TRAIN / 1e12, 1)
-               if args.clip == "ViT-B/32" and args.frames == 12 else None,
-               "mfma_frac_whole_step": round(value * FLOP_PER_PAIR_EXECUTED / 1e12 / (world * MFMA_PEAK_TFLOPS), 4)
-               if args.clip == "ViT-B/32" and args.frames == 12 else None,
-               "final_loss": round(final_loss, 4), "roofline": roof}
+               "gflop_per_pair_reference_formulation": round(per_pair / 1e9, 2) if per_pair else None,
+               "step_tflops": round(value * per_pair_exec / 1e12, 1) if per_pair_exec else None,
+               "step_tflops_reference_formulation": round(value * per_pair / 1e12, 1) if per_pair else None,
+               "mfma_frac_whole_step": round(value * (per_pair_exec or per_pair) / 1e12 / (world * MFMA_PEAK_TFLOPS), 4) if per_pair else None,
+               "final_loss": round(final_loss, 4), "roofline": roof, "vit_forward": vit_forward}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.frames, args.length)
+            out["cpu_baseline"] = cpu_baseline(12, 32)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -340,26 +340,46 @@ class MocoLossFn(torch.autograd.Function):
         return dq, None, None, None, None
 
 
+def _mlm_capacity(n, p):
+    """rows the MLM head is evaluated on: every position for small inputs, otherwise the expected number of labelled
+    positions plus eight standard deviations of Binomial(n, p) (exceeded with probability < 1e-15)."""
+    import math
+    if n <= 4096 or p <= 0 or p >= 1:
+        return n
+    return min(n, int(n * p + 8.0 * math.sqrt(n * p * (1.0 - p))) + 16)
+
+
 class MlmHeadFn(torch.autograd.Function):
     """BertLMPredictionHead + cross-entropy with ignore_index -100 (modules/module_cross.py:308-357,
     modules/modeling.py:171-179): dense, erf-GELU, TF-LayerNorm(1e-12), decoder to the vocabulary, mean CE.
 
     The reference runs the head over all b*L positions and lets the loss ignore the ~85 % whose label is -100; neither
     the loss nor any gradient depends on those rows, so the head (a [rows, 512] x [512, 49408] fp32 GEMM and its two
-    backward GEMMs) is evaluated on the labelled rows only.  Their number sizes the launches, hence one host read of the
-    row list per call (torch.nonzero)."""
+    backward GEMMs) is evaluated on the labelled rows only.  Their number is data dependent; to keep the host from
+    reading it (a stall of the launch stream every step) the labelled rows are compacted on the device into a buffer of
+    fixed capacity (_mlm_capacity: mean + 8 sigma of the mask's binomial), the unused slots carry label -100, and a
+    labelled count above the capacity raises the device error flag (ops.raise_on_device_errors) instead of going unnoticed."""
 
     @staticmethod
-    def forward(ctx, hidden, labels, dw, db, lnw, lnb, decw, decb):
+    def forward(ctx, hidden, labels, dw, db, lnw, lnb, decw, decb, mask_prob=0.15):
         x_all = hidden.contiguous().view(-1, hidden.shape[-1])
         labels = labels.contiguous().view(-1)
-        rows = torch.nonzero(labels >= 0).view(-1)
-        ctx.shape, ctx.n = hidden.shape, int(rows.numel())
-        if ctx.n == 0:                       # nothing masked: the loss is 0 (sum over no rows / max(count, 1)), all gradients 0
-            ctx.save_for_backward(dw, lnw, decw, decb)
-            return x_all.new_zeros(())
-        x = x_all.index_select(0, rows)
-        lab = labels.index_select(0, rows)
+        n = labels.numel()
+        cap = _mlm_capacity(n, mask_prob)
+        flag = labels >= 0
+        pos = torch.cumsum(flag.to(torch.int64), 0) - 1                       # slot of every labelled row, in order
+        keep = flag & (pos < cap)
+        # slot -> row (unused slots point at the dump row n); every tensor below has a static shape: no host read
+        rows = torch.full((cap + 1,), n, dtype=torch.int64, device=labels.device)
+        rows.scatter_(0, torch.where(keep, pos, torch.full_like(pos, cap)), torch.arange(n, device=labels.device))
+        rows = rows[:cap]
+        if cap < n:
+            ops.device_error_flag(labels.device).add_((pos[-1] >= cap).to(torch.int32))
+        used = rows < n
+        gather = rows.clamp(max=n - 1)
+        x = x_all.index_select(0, gather)
+        lab = torch.where(used, labels.index_select(0, gather), torch.full_like(rows, -100))
+        ctx.shape = hidden.shape
         a = ops.linear_f32(x, dw, bias=db)
         g = ops.gelu_erf_fwd(a)
         t, mean, rstd = ops.layernorm_fwd(g, lnw, lnb, 1e-12)
@@ -370,10 +390,6 @@ class MlmHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        if ctx.n == 0:
-            dw, lnw, decw, decb = ctx.saved_tensors
-            return (dw.new_zeros(ctx.shape), None, torch.zeros_like(dw), dw.new_zeros(dw.shape[0]), torch.zeros_like(lnw),
-                    torch.zeros_like(lnw), torch.zeros_like(decw), torch.zeros_like(decb))
         x, lab, rows, dw, lnw, decw, a, g, t, mean, rstd, logits, lse, count = ctx.saved_tensors
         dlogits = ops.ce_bwd_(logits, lab, lse, gout, count)
         d_decw = ops.wgrad_f32(dlogits, t)
@@ -384,5 +400,7 @@ class MlmHeadFn(torch.autograd.Function):
         d_dw = ops.wgrad_f32(da, x)
         d_db = ops.colsum(da)
         dx_rows = ops.dgrad_f32(da, dw)
-        dx = dx_rows.new_zeros(ctx.shape[:-1].numel(), ctx.shape[-1]).index_copy_(0, rows, dx_rows)
-        return dx.view(ctx.shape), None, d_dw, d_db, d_lnw, d_lnb, d_decw, d_decb
+        n = ctx.shape[:-1].numel()
+        # unused slots (zero gradient: their label is -100) all land in the dump row n
+        dx = dx_rows.new_zeros(n + 1, ctx.shape[-1]).index_copy_(0, rows, dx_rows)[:n]
+        return dx.view(ctx.shape), None, d_dw, d_db, d_lnw, d_lnb, d_decw, d_decb, None

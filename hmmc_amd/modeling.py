@@ -275,7 +275,8 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
     def calculate_mlm_loss(self, sequence_output_mlm, labels):
         c = self.cls
         return Fn.MlmHeadFn.apply(sequence_output_mlm, labels, c.transform.dense.weight, c.transform.dense.bias,
-                                  c.transform.LayerNorm.weight, c.transform.LayerNorm.bias, c.decoder.weight, c.bias)
+                                  c.transform.LayerNorm.weight, c.transform.LayerNorm.bias, c.decoder.weight, c.bias,
+                                  float(self.mlm_probability))
 
     def forward(self, video_data, video_frame, tag_ids, tag_mask, title_ids, title_mask, global_step):
         tag_ids = tag_ids.view(-1, tag_ids.shape[-1])

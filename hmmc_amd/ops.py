@@ -246,7 +246,8 @@ def raise_on_device_errors(device=None):
         f = _ERR_FLAGS.get(k)
         if f is not None and int(f.item()) != 0:
             f.zero_()
-            raise IndexError("token id outside the embedding table (hmmc_text_embed); the row was embedded as zeros")
+            raise IndexError("a device-side check failed since the last call: a token id outside the embedding table (the row was "
+                             "embedded as zeros), or more MLM-labelled positions than the head's row buffer holds")
 
 
 def attention_f16_fwd(qkv, nseq, L, H, causal):

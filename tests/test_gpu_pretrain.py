@@ -89,6 +89,36 @@ def test_mlm_head_fn_vs_oracle():
     assert P["cls.decoder.weight"].grad is not None and P["cls.transform.dense.weight"].grad is not None
 
 
+def test_mlm_head_row_buffer_capacity_and_overflow_flag():
+    """Above 4 096 positions the head runs on a fixed-capacity buffer of compacted rows (no host read of the labelled
+    count): same loss and gradients as the all-rows evaluation, and a count beyond the capacity raises the device flag."""
+    sd = synth.pretrain_state(synth.TINY, 16, 4)
+    P = {k: v.to(DEV) for k, v in sd.items() if k.startswith("cls.")}
+    args = (P["cls.transform.dense.weight"], P["cls.transform.dense.bias"], P["cls.transform.LayerNorm.weight"],
+            P["cls.transform.LayerNorm.bias"], P["cls.decoder.weight"], P["cls.bias"])
+    n = 6000
+    hidden = synth.normal("mlm.cap.hidden", (n, 512), 0.5).to(DEV)
+    gen = torch.Generator().manual_seed(3)
+    labels = torch.where(torch.rand(n, generator=gen) < 0.15, torch.randint(0, 49408, (n,), generator=gen), torch.full((n,), -100))
+    labels = labels.to(DEV)
+    assert Fn._mlm_capacity(n, 0.15) < n // 4
+    outs = []
+    for prob in (0.15, 1.0):                       # 1.0: capacity = every row
+        h = hidden.clone().requires_grad_()
+        w = [a.clone().requires_grad_() for a in args]
+        loss = Fn.MlmHeadFn.apply(h, labels, *w, prob)
+        loss.backward()
+        outs.append((loss.detach(), h.grad, w[4].grad, w[0].grad))
+    ops.raise_on_device_errors()                   # nothing flagged
+    close(outs[0][0], outs[1][0], 1e-6, 1e-6, "loss")
+    close(outs[0][1], outs[1][1], 1e-7, 1e-4, "dhidden")
+    close(outs[0][2], outs[1][2], 1e-7, 1e-4, "ddecoder")
+    close(outs[0][3], outs[1][3], 1e-7, 1e-4, "ddense")
+    Fn.MlmHeadFn.apply(hidden, torch.full((n,), 7, dtype=torch.long, device=DEV), *args, 0.15)
+    with pytest.raises(IndexError):
+        ops.raise_on_device_errors()
+
+
 def test_pretrain_steps_vs_reference_golden():
     """5 steps of main_pretrain.py's loop; K=16, B=4 wraps the queue pointer at step 4."""
     from hmmc_amd.modeling import BirdPreTrainedModel
