@@ -28,7 +28,7 @@ SIGNATURES = {
     "hmmc_layernorm_bwd": ("pppppppppppiilipzp", "i"),
     "hmmc_colsum_workspace": ("ii", "z"),
     "hmmc_colsum": ("ppiiliiipzp", "i"),
-    "hmmc_patchify_u8": ("ppiiiippp", "i"),
+    "hmmc_patchify_u8": ("pppiiiippp", "i"),
     "hmmc_patchify": ("ppiiiip", "i"),
     "hmmc_vit_embed": ("pppliip", "i"),
     "hmmc_text_embed": ("ppppliilpp", "i"),

@@ -25,9 +25,32 @@ static inline int hmmc_launch_status() {
   return e == hipSuccess ? HMMC_OK : HMMC_ERR_LAUNCH;
 }
 
-// kernels that ask for more than 64 KiB of dynamic LDS must opt in once
-static inline void hmmc_allow_lds(const void* kernel, int bytes) {
+#define HMMC_MAX_DEVICES 16
+static inline int hmmc_current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev >= 0 && dev < HMMC_MAX_DEVICES ? dev : 0;
+}
+
+// kernels that ask for more than 64 KiB of dynamic LDS must opt in, once per device (`done` = the call site's own
+// per-device flags; a racing second thread merely repeats the idempotent call)
+static inline void hmmc_allow_lds(const void* kernel, int bytes, bool (&done)[HMMC_MAX_DEVICES]) {
+  const int dev = hmmc_current_device();
+  if (done[dev]) return;
   (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done[dev] = true;
+}
+
+// compute units of the current device (queried once per device)
+static inline int hmmc_num_cus() {
+  static int cus[HMMC_MAX_DEVICES] = {0};
+  const int dev = hmmc_current_device();
+  if (cus[dev] == 0) {
+    int n = 0;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cus[dev] = n > 0 ? n : 256;
+  }
+  return cus[dev];
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

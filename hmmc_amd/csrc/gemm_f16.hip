@@ -634,13 +634,9 @@ struct TileCfg { int bm, bn, splitk; };
 
 int g_reserved_cus = 0;      // hmmc_gemm_reserve_cus
 
-// compute units the persistent grids may occupy
+// compute units the persistent grids may occupy on the current device
 int gemm_cus() {
-  static const int num_cu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
+  const int num_cu = hmmc_num_cus();
   return num_cu - g_reserved_cus > 8 ? num_cu - g_reserved_cus : 8;
 }
 
@@ -677,8 +673,8 @@ template <bool AK, bool BK, int BM, int BN, int WM, int WN, int EPI>
 void launch_one(const GemmArgs& p, dim3 grid, hipStream_t stream) {
   constexpr int SMEM = 2 * (BM + BN) * BKT * 2 + WM * WN * EPI_LDS_PER_WAVE;      // two stages + the epilogue's LDS tiles
   if (SMEM > 64 * 1024) {
-    static bool once = (hmmc_allow_lds((const void*)gemm_f16_kernel<AK, BK, BM, BN, WM, WN, EPI>, SMEM), true);
-    (void)once;
+    static bool done[HMMC_MAX_DEVICES] = {false};
+    hmmc_allow_lds((const void*)gemm_f16_kernel<AK, BK, BM, BN, WM, WN, EPI>, SMEM, done);
   }
   hipLaunchKernelGGL((gemm_f16_kernel<AK, BK, BM, BN, WM, WN, EPI>), grid, dim3(64 * WM * WN), SMEM, stream, p);
 }
@@ -714,14 +710,18 @@ void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stre
 
 // ---- optional live timing (bench.py): HIP events recorded on the launch stream around every hmmc_gemm_f16 call.
 // Process-wide and off by default; the only mutable state in the library, used by the benchmark alone.
+#include <atomic>
+#include <mutex>
 #include <vector>
 namespace {
 struct GemmProfRec { hipEvent_t e0, e1; double flops, bytes; int layout; };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;                 // hmmc_gemm_f16 may be called from several host threads (autograd, one per device)
 std::vector<GemmProfRec> g_prof;
 }  // namespace
 
 extern "C" int hmmc_gemm_profile_start(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_prof.clear();
   g_prof_on = true;
@@ -733,6 +733,7 @@ extern "C" int hmmc_gemm_profile_start(void) {
 extern "C" int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seconds, long* launches) {
   g_prof_on = false;
   if (!flops || !bytes || !seconds || !launches) return HMMC_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int i = 0; i < 3; ++i) { flops[i] = 0; bytes[i] = 0; seconds[i] = 0; launches[i] = 0; }
   if (hipDeviceSynchronize() != hipSuccess) return HMMC_ERR_LAUNCH;
   for (auto& r : g_prof) {
@@ -827,6 +828,6 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, (half_t*)C, M, N,
                        ldc, splitk);
   }
-  if (g_prof_on) { (void)hipEventRecord(rec.e1, stream); g_prof.push_back(rec); }
+  if (rec.e0) { (void)hipEventRecord(rec.e1, stream); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(rec); }
   return hmmc_launch_status();
 }

@@ -422,11 +422,7 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
   p.bvec = !(b_ld & 3) && !((uintptr_t)B & 15);
   p.cvec = !(ldc & 3) && !((uintptr_t)C & 15) && (!aux_out || !((uintptr_t)aux_out & 15));
   long blocks = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-  static const int num_cu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
+  const int num_cu = hmmc_num_cus();
   // Two kernels.  The 64x64 LDS kernel runs one 16-deep K-step per ~0.4 us while a workgroup is alone on its CU (0.2 us of
   // MFMA plus the in-order issue of its staging and the barrier) and ~0.6x that per further co-resident workgroup, so a
   // problem with few tiles is bound by the length of K; the split-K 16x32 kernel has no such chain but re-reads its operands

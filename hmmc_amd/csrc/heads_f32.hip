@@ -422,8 +422,8 @@ extern "C" int hmmc_temporal_attention_fwd(const float* qkv, float* out, float* 
                                            hipStream_t stream) {
   if (!qkv || !out || !probs || b <= 0 || F <= 0 || F > 64 || H <= 0) return HMMC_ERR_ARG;
   size_t lds = (size_t)(3 * F * 65 + F * F) * sizeof(float);
-  static bool once = (hmmc_allow_lds((const void*)tattn_fwd_kernel, 160 * 1024 - 4096), true);
-  (void)once;
+  static bool done[HMMC_MAX_DEVICES] = {false};
+  hmmc_allow_lds((const void*)tattn_fwd_kernel, 160 * 1024 - 4096, done);
   hipLaunchKernelGGL(tattn_fwd_kernel, dim3(b * H), dim3(64), lds, stream, qkv, out, probs, F, H, causal);
   return hmmc_launch_status();
 }
@@ -432,8 +432,8 @@ extern "C" int hmmc_temporal_attention_bwd(const float* qkv, const float* probs,
                                            int F, int H, hipStream_t stream) {
   if (!qkv || !probs || !dout || !dqkv || b <= 0 || F <= 0 || F > 64 || H <= 0) return HMMC_ERR_ARG;
   size_t lds = (size_t)(4 * F * 65 + 2 * F * F) * sizeof(float);
-  static bool once = (hmmc_allow_lds((const void*)tattn_bwd_kernel, 160 * 1024 - 4096), true);
-  (void)once;
+  static bool done[HMMC_MAX_DEVICES] = {false};
+  hmmc_allow_lds((const void*)tattn_bwd_kernel, 160 * 1024 - 4096, done);
   hipLaunchKernelGGL(tattn_bwd_kernel, dim3(b * H), dim3(64), lds, stream, qkv, probs, dout, dqkv, F, H);
   return hmmc_launch_status();
 }

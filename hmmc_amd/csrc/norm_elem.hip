@@ -304,8 +304,10 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 // (dataloaders/dataloader_msrvtt_retrieval.py:242-247: ToTensor = x / 255 in fp32, Normalize = (x - mean[c]) / std[c] in
 // fp32, then the model's image.type(fp16)): a quarter of the input bytes of the fp32 path.
 struct PixNorm { float mean[3], std[3]; };
-__global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* __restrict__ img, half_t* __restrict__ out,
-                                                          int nframes, int H, int W, int p, int g, PixNorm nm) {
+// frame_index (optional): output frame n is read from stored frame frame_index[n] (frame sampling, no gathered copy)
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* __restrict__ img, const int* __restrict__ frame_index,
+                                                          half_t* __restrict__ out, int nframes, int H, int W, int p, int g,
+                                                          PixNorm nm) {
   const int L = g * g + 1;
   const int kc = 3 * p * p / 8;
   const long total = (long)nframes * L * kc;
@@ -323,7 +325,8 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* _
       int per_c = p * p / 8;
       int c = ch / per_c, rem = ch % per_c;
       int ky = rem / (p / 8), kx = (rem % (p / 8)) * 8;
-      const unsigned char* src = img + (((n * 3 + c) * H + gy * p + ky) * (long)W + gx * p + kx);
+      const long ns = frame_index ? (long)frame_index[n] : n;
+      const unsigned char* src = img + (((ns * 3 + c) * H + gy * p + ky) * (long)W + gx * p + kx);
       const uint2 raw = *reinterpret_cast<const uint2*>(src);
       const float m = nm.mean[c], sd = nm.std[c];
 #pragma unroll
@@ -578,15 +581,15 @@ extern "C" int hmmc_patchify(const float* img, void* out, int nframes, int H, in
   return hmmc_launch_status();
 }
 
-extern "C" int hmmc_patchify_u8(const void* img, void* out, int nframes, int H, int W, int patch, const float* mean3,
-                                const float* std3, hipStream_t stream) {
+extern "C" int hmmc_patchify_u8(const void* img, const int* frame_index, void* out, int nframes, int H, int W, int patch,
+                                const float* mean3, const float* std3, hipStream_t stream) {
   if (!img || !out || !mean3 || !std3 || nframes <= 0) return HMMC_ERR_ARG;      // mean3 / std3: HOST arrays of 3 floats
   if (patch % 8 || H % patch || W % patch || H != W || (W & 7) || ((uintptr_t)img & 7)) return HMMC_ERR_UNSUPPORTED;
   int g = H / patch;
   PixNorm nm;
   for (int c = 0; c < 3; ++c) { nm.mean[c] = mean3[c]; nm.std[c] = std3[c]; }
   long total = (long)nframes * (g * g + 1) * (3 * patch * patch / 8);
-  hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, (const unsigned char*)img,
+  hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, (const unsigned char*)img, frame_index,
                      (half_t*)out, nframes, H, W, patch, g, nm);
   return hmmc_launch_status();
 }

@@ -9,6 +9,9 @@
 //   scratch : hmmc_tower_bwd_scratch_bytes() for the backward's transient gradients
 //   grads   : nlayers x 12 pointers, written (not accumulated)
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 extern "C" {
 int hmmc_gemm_f16(const void*, const void*, void*, int, int, int, int, int, int, int, int, const void*, const void*, void*,
@@ -205,21 +208,26 @@ extern "C" int hmmc_tower_fwd(const void* x, void* y, const void* const* params,
 
 // dx = d tower / d x (dy given), grads[nlayers*12] written.  x0 is the tower input given to hmmc_tower_fwd.
 namespace {
-// events of one backward call: main -> weight-gradient stream ("operand ready") and back ("operand no longer read")
+// Events between the main and the weight-gradient stream ("operand ready" and back, "operand no longer read"): one set per
+// (main stream, weight-gradient stream) pair, created on the pair's FIRST hmmc_tower_bwd call and kept for the life of the
+// process (hipEventCreate is the only allocation the library ever makes besides that of hmmc_gemm_profile_start; a
+// recorded event may be recorded again - a wait already enqueued keeps the record it was enqueued against).
 struct WgradSync {
   hipEvent_t ready = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool done_set[4] = {false, false, false, false};
   bool ok = false;
-  explicit WgradSync(bool two) {
-    if (!two) return;
+  WgradSync() {
     ok = hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < 4; ++k) ok = ok && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
   }
-  ~WgradSync() {
-    if (ready) (void)hipEventDestroy(ready);
-    for (int k = 0; k < 4; ++k) if (done[k]) (void)hipEventDestroy(done[k]);
-  }
 };
+std::mutex g_sync_mu;
+std::map<std::pair<hipStream_t, hipStream_t>, WgradSync*> g_sync;
+WgradSync* wgrad_sync_for(hipStream_t s, hipStream_t sw) {
+  std::lock_guard<std::mutex> lk(g_sync_mu);
+  WgradSync*& e = g_sync[{s, sw}];
+  if (!e) e = new WgradSync();
+  return e;
+}
 }  // namespace
 
 // wgrad_stream (optional): the four weight-gradient GEMMs of every layer are leaves of the backward pass; given a second
@@ -255,24 +263,25 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
   void* wws = (char*)workspace + gen + part_bytes;
   hipStream_t sw = wgrad_stream ? wgrad_stream : s;
   const bool two = sw != s;
-  WgradSync sync(two);
-  if (two && !sync.ok) return HMMC_ERR_LAUNCH;
+  WgradSync* const syncp = two ? wgrad_sync_for(s, sw) : nullptr;
+  if (two && !syncp->ok) return HMMC_ERR_LAUNCH;
+  bool done_set[4] = {false, false, false, false};
   // weight gradient k of a layer (0: c_proj <- g_in, 1: c_fc <- dh, 2: out_proj <- dx1, 3: in_proj <- dqkv)
   auto side_wgrad = [&](int k, const void* dyk, const void* xk, void* dW, int Np, int Kp, int rows = 0, int ldy = 0,
                         int ldx = 0) -> int {
     if (two) {
-      if (hipEventRecord(sync.ready, s) != hipSuccess || hipStreamWaitEvent(sw, sync.ready, 0) != hipSuccess) return HMMC_ERR_LAUNCH;
+      if (hipEventRecord(syncp->ready, s) != hipSuccess || hipStreamWaitEvent(sw, syncp->ready, 0) != hipSuccess) return HMMC_ERR_LAUNCH;
     }
     int rc = wgrad(f32, dyk, xk, dW, rows ? rows : (int)T, Np, Kp, two ? wws : workspace, two ? wws_bytes : gen, sw, ldy, ldx);
     if (rc == 0 && two) {
-      if (hipEventRecord(sync.done[k], sw) != hipSuccess) return HMMC_ERR_LAUNCH;
-      sync.done_set[k] = true;
+      if (hipEventRecord(syncp->done[k], sw) != hipSuccess) return HMMC_ERR_LAUNCH;
+      done_set[k] = true;
     }
     return rc;
   };
   // the chain on `s` is about to overwrite the operand weight gradient k read (scratch buffers are reused every layer)
   auto before_overwrite = [&](int k) -> int {
-    if (two && sync.done_set[k] && hipStreamWaitEvent(s, sync.done[k], 0) != hipSuccess) return HMMC_ERR_LAUNCH;
+    if (two && done_set[k] && hipStreamWaitEvent(s, syncp->done[k], 0) != hipSuccess) return HMMC_ERR_LAUNCH;
     return 0;
   };
   const void* g_in = dy;
@@ -344,7 +353,7 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
     g_in = g_out;
   }
   if (two) {                                     // hand the weight gradients back in `s` order
-    if (hipEventRecord(sync.ready, sw) != hipSuccess || hipStreamWaitEvent(s, sync.ready, 0) != hipSuccess) return HMMC_ERR_LAUNCH;
+    if (hipEventRecord(syncp->ready, sw) != hipSuccess || hipStreamWaitEvent(s, syncp->ready, 0) != hipSuccess) return HMMC_ERR_LAUNCH;
   }
   return HMMC_OK;
 }

@@ -42,12 +42,18 @@ def _dgrad16(dy, w, aux_in=None, epilogue=0):
 
 class VitEmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, video4d, conv_w, cls, pos, ln_w, ln_b):
-        n = video4d.shape[0]
+    def forward(ctx, video4d, conv_w, cls, pos, ln_w, ln_b, frame_index=None):
+        n = video4d.shape[0] if frame_index is None else frame_index.numel()
         D, _, p, _ = conv_w.shape
         L = pos.shape[0]
-        # [n*L, 3pp] fp16, class rows zero; uint8 frames are normalised on the fly (CLIP mean / std)
-        patches = ops.patchify_u8(video4d, p) if video4d.dtype == torch.uint8 else ops.patchify(video4d, p)
+        # [n*L, 3pp] fp16, class rows zero; uint8 frames are normalised on the fly (CLIP mean / std) and, with a frame
+        # index, picked out of the stored frames in place (the loader's frame sampling)
+        if video4d.dtype == torch.uint8:
+            patches = ops.patchify_u8(video4d, p, frame_index=frame_index)
+        else:
+            if frame_index is not None:
+                raise TypeError("frame sampling on the device takes the stored uint8 frames")
+            patches = ops.patchify(video4d, p)
         x0 = ops.gemm_f16(patches, conv_w.view(D, -1), n * L, D, 3 * p * p)
         ops.vit_embed_(x0, cls, pos, L)
         x, mean, rstd = ops.layernorm_fwd(x0, ln_w, ln_b, 1e-5)
@@ -62,7 +68,7 @@ class VitEmbedFn(torch.autograd.Function):
         dx0, dlw, dlb = ops.layernorm_bwd(dx.contiguous(), x0, ln_w, mean, rstd)
         dconv = _wgrad16(dx0, patches).view(conv_w.shape)
         dpos = ops.colsum(dx0.view(n, L * D), out_dtype=torch.float32, round_f16=True).view(L, D)
-        return None, dconv, dpos[0].clone(), dpos, dlw, dlb
+        return None, dconv, dpos[0].clone(), dpos, dlw, dlb, None
 
 
 class TextEmbedFn(torch.autograd.Function):

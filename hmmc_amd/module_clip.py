@@ -118,12 +118,12 @@ class VisualTransformer(nn.Module):
         h = self.hidden_tokens(x)
         return h.view(n, self.tokens, -1)
 
-    def hidden_tokens(self, x, lead_only=False):
-        n = x.shape[0]
+    def hidden_tokens(self, x, lead_only=False, frame_index=None):
+        n = x.shape[0] if frame_index is None else frame_index.numel()
         # the kernel casts fp32 pixels to fp16 while patchifying (image.type(fp16)); raw uint8 frames are normalised there too
         x = x.contiguous() if x.dtype == torch.uint8 else x.float().contiguous()
         t = Fn.VitEmbedFn.apply(x, self.conv1.weight, self.class_embedding, self.positional_embedding,
-                                self.ln_pre.weight, self.ln_pre.bias)
+                                self.ln_pre.weight, self.ln_pre.bias, frame_index)
         return self.transformer(t, n, self.tokens, lead_only)
 
 
@@ -185,10 +185,18 @@ class CLIP(nn.Module):
         elif os.path.isfile(pretrained_clip_name):
             path = pretrained_clip_name
         if path is not None:
+            # A plain state_dict file loads with the weights-only unpickler (nothing in the file is executed).  OpenAI's
+            # ViT-B-32.pt is a TorchScript archive (the reference opens it with torch.jit.load, modules/module_clip.py:425-
+            # 439): deserialising it runs the archive's code, so it is taken only for a zip archive that weights_only
+            # refused AND with HMMC_ALLOW_TORCHSCRIPT_CHECKPOINT=1 set; only its state_dict is kept.
             try:
-                return torch.jit.load(path, map_location="cpu").eval().state_dict()
-            except RuntimeError:
                 return torch.load(path, map_location="cpu", weights_only=True)
+            except Exception as err:
+                import zipfile
+                if not (zipfile.is_zipfile(path) and os.environ.get("HMMC_ALLOW_TORCHSCRIPT_CHECKPOINT") == "1"):
+                    raise RuntimeError(f"{path}: not loadable as a weights-only state_dict ({type(err).__name__}: {err}); a "
+                                       "TorchScript archive needs HMMC_ALLOW_TORCHSCRIPT_CHECKPOINT=1") from err
+                return torch.jit.load(path, map_location="cpu").eval().state_dict()
         if pretrained_clip_name in synth.NAMED:
             dims = synth.NAMED[pretrained_clip_name]
             return synth.clip_state_from(synth.finetune_state(dims, use_temp=False), dims)

@@ -117,10 +117,15 @@ class VisualEncoder(nn.Module):
     def dtype(self):
         return self.visual.conv1.weight.dtype
 
-    def forward(self, video, video_frames=None):
+    def forward(self, video, video_frames=None, frame_index=None):
+        """frame_index (int32 [bs, frames] from hmmc_amd.sampling.batch_frame_index): `video` then holds every STORED frame,
+        uint8 [bs, stored, 3, H, W], and the sampled ones are read in place by the patch kernel."""
         bs, frames, channel, h, w = video.shape
         video = video.reshape(bs * frames, channel, h, w)
-        frame_output = self.encode_image(video, video_frame=frames).view(bs, frames, -1)
+        if frame_index is not None:
+            frames = frame_index.shape[1]
+            frame_index = frame_index.reshape(-1).contiguous()
+        frame_output = self.encode_image(video, video_frame=frames, frame_index=frame_index).view(bs, frames, -1)
         if self.use_temp:
             if frames > self.frame_position_embeddings.weight.shape[0]:
                 raise ValueError("more frames than max_position_embeddings")
@@ -131,13 +136,13 @@ class VisualEncoder(nn.Module):
             visual_output = Fn.TemporalFn.apply(frame_output, 0, None)
         return visual_output, frame_output
 
-    def encode_image(self, image, return_hidden=False, video_frame=-1):
+    def encode_image(self, image, return_hidden=False, video_frame=-1, frame_index=None):
         """ln_post(hidden) @ proj, CLS row, .float() (reference modules/module_cross.py:222-237).  Only the CLS
         rows are normalised and projected unless return_hidden asks for all tokens."""
-        n = image.shape[0]
+        n = image.shape[0] if frame_index is None else frame_index.numel()
         L = self.visual.tokens
         # without return_hidden only the class-token row of the last block is consumed: its per-token half runs on that row alone
-        tokens = self.visual.hidden_tokens(image, lead_only=not return_hidden)
+        tokens = self.visual.hidden_tokens(image, lead_only=not return_hidden, frame_index=frame_index)
         v = self.visual
         if return_hidden:
             hidden = Fn.LnProjFn.apply(tokens, None, v.ln_post.weight, v.ln_post.bias, v.proj).view(n, L, -1)

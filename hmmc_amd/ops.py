@@ -188,16 +188,20 @@ CLIP_PIXEL_MEAN = (0.48145466, 0.4578275, 0.40821073)      # dataloaders/rawvide
 CLIP_PIXEL_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def patchify_u8(video4d_u8, patch, mean=CLIP_PIXEL_MEAN, std=CLIP_PIXEL_STD):
-    """uint8 [n,3,H,W] -> fp16 patches as patchify(), with x/255 and the per-channel normalisation fused in."""
+def patchify_u8(video4d_u8, patch, mean=CLIP_PIXEL_MEAN, std=CLIP_PIXEL_STD, frame_index=None):
+    """uint8 [n,3,H,W] -> fp16 patches as patchify(), with x/255 and the per-channel normalisation fused in.
+    frame_index (int32 [m] on the device): patches of the m frames video4d_u8[frame_index[i]] instead (frame sampling)."""
     import ctypes
     _chk(video4d_u8, torch.uint8, "video")
     n, c, H, W = video4d_u8.shape
     assert c == 3
+    if frame_index is not None:
+        _chk(frame_index, torch.int32, "frame_index")
+        n = frame_index.numel()
     g = H // patch
     out = torch.empty((n * (g * g + 1), 3 * patch * patch), dtype=torch.float16, device=video4d_u8.device)
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
-    call("hmmc_patchify_u8", ptr(video4d_u8), ptr(out), n, H, W, patch, m3, s3)
+    call("hmmc_patchify_u8", ptr(video4d_u8), ptr(frame_index), ptr(out), n, H, W, patch, m3, s3)
     return out
 
 

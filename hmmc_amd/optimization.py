@@ -140,7 +140,7 @@ class BertAdam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        rows, frows = [], []
+        rows, frows = [], {}
         dev = None
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
@@ -160,23 +160,27 @@ class BertAdam(Optimizer):
                 else:
                     lr_s = group["lr"]
                 dev = p.device
-                # one hyper-parameter row per distinct (group, step count): parameters of a group normally share both
+                # one hyper-parameter row per DISTINCT (group, step count), wherever its parameters sit in the list (a
+                # parameter that skipped steps - grad None for a while, partial optimizer state - has its own row)
                 hp = (lr_s, group["weight_decay"], group["b1"], group["b2"], group["e"], group["max_grad_norm"],
                       1 - group["b1"], 1 - group["b2"])
-                if not frows or frows[-1] != hp:
-                    frows.append(hp)
+                gi_row = frows.setdefault(hp, len(frows))
                 rows.append((p.data_ptr(), p.grad.data_ptr(), state["next_m"].data_ptr(), state["next_v"].data_ptr(),
-                             p.numel(), _dtype_flag(p), len(frows) - 1))
+                             p.numel(), _dtype_flag(p), gi_row))
                 state["step"] += 1
         if not rows:
             return loss
         if dev.type != "cuda":
             raise RuntimeError("hmmc_amd.BertAdam runs on the GPU only (no CPU fallback)")
         if self._table is None:
-            self._table = _TensorTable(dev)
-        if len(frows) > 32:
-            raise ValueError("BertAdam (HIP): more than 32 distinct (group, step) hyper-parameter rows")
-        tbl = self._table.build(rows)
-        hp_host = (ctypes.c_float * (8 * len(frows)))(*[x for row in frows for x in row])
-        call("hmmc_mt_bertadam", ptr(tbl.tab), hp_host, len(frows), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T)
+            self._table = {}
+        hps = list(frows)                                   # insertion order = row index
+        MAXG = 32                                           # hyper-parameter rows one launch takes (kernel MAX_GROUPS)
+        for part in range((len(hps) + MAXG - 1) // MAXG):   # normally one launch; more only with > 32 distinct rows
+            lo = part * MAXG
+            sel = rows if len(hps) <= MAXG else [r[:6] + (r[6] - lo,) for r in rows if lo <= r[6] < lo + MAXG]
+            tbl = self._table.setdefault(part, _TensorTable(dev)).build(sel)
+            hp_part = hps[lo:lo + MAXG]
+            hp_host = (ctypes.c_float * (8 * len(hp_part)))(*[x for row in hp_part for x in row])
+            call("hmmc_mt_bertadam", ptr(tbl.tab), hp_host, len(hp_part), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T)
         return loss

@@ -7,8 +7,13 @@
  *
  * Conventions: plain device pointers and sizes; the caller owns every buffer (outputs and
  * workspaces are pre-allocated; hmmc_*_workspace() returns the bytes an op needs); kernels are
- * enqueued on `stream` (a hipStream_t) and never synchronise or allocate; no global mutable
- * state.  Return value: 0 on success, HMMC_ERR_* (< 0) otherwise — nothing is launched on error.
+ * enqueued on `stream` (a hipStream_t) and never synchronise; no device memory is ever allocated.
+ * Re-entrant across host threads and devices (device properties and LDS opt-ins are kept per
+ * device).  Process-wide state, all of it listed here: (1) hmmc_gemm_reserve_cus(n), a setting;
+ * (2) the benchmark timing switch hmmc_gemm_profile_start/stop (mutex-protected; creates HIP events
+ * while on, and stop() synchronises the device); (3) five HIP events per (stream, weight-gradient
+ * stream) pair, created by that pair's first hmmc_tower_bwd call and reused by every later one.
+ * Return value: 0 on success, HMMC_ERR_* (< 0) otherwise — nothing is launched on error.
  * fp16 buffers are IEEE binary16; "tokens" are rows of a row-major [tokens, D] matrix with each
  * sequence's L tokens contiguous.
  */
@@ -88,9 +93,11 @@ int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int in_dtype, i
  * fp32 NCHW frames -> fp16 [nframes*(g*g+1), 3*patch*patch]; row 0 of each frame is zero (class slot). */
 int hmmc_patchify(const float* img, void* out, int nframes, int H, int W, int patch, hmmc_stream_t stream);
 /* The same from uint8 NCHW frames with the loader's normalisation fused in (dataloaders/dataloader_msrvtt_retrieval.py:
- * 242-247: x/255, (x - mean[c]) / std[c] in fp32, then fp16): a quarter of the input bytes.  mean3 / std3 are HOST arrays. */
-int hmmc_patchify_u8(const void* img, void* out, int nframes, int H, int W, int patch, const float* mean3,
-                     const float* std3, hmmc_stream_t stream);
+ * 242-247: x/255, (x - mean[c]) / std[c] in fp32, then fp16): a quarter of the input bytes.  mean3 / std3 are HOST arrays.
+ * frame_index (device int32 [nframes], may be NULL): output frame n is read from stored frame frame_index[n] of img - the
+ * loader's frame sampling (:296-312 sample_slice) applied in place, without a gathered copy of the chosen frames. */
+int hmmc_patchify_u8(const void* img, const int* frame_index, void* out, int nframes, int H, int W, int patch,
+                     const float* mean3, const float* std3, hmmc_stream_t stream);
 /* In place on the patch-GEMM output: class_embedding into row 0, + positional_embedding
  * (modules/module_clip.py:311-312), with the reference's fp16 rounding points. */
 int hmmc_vit_embed(void* x, const float* cls, const float* pos, long rows, int L, int D, hmmc_stream_t stream);

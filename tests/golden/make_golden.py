@@ -262,6 +262,43 @@ def fx_multisent(mclip, mmodel, mopt, mmetrics):
     save("multisent", **out)
 
 
+def fx_frame_sampling(mclip, mmodel, mopt, mmetrics):
+    """Frame indices the reference's loader draws (dataloaders/dataloader_msrvtt_retrieval.py:296-312, `uniform`,
+    `random`, `uniform_random` out of g_lmdb_frames stored frames), recorded by driving MSRVTT_TrainDataLoader._get_rawvideo itself with a fake
+    LMDB transaction.  lmdb / cv2 / torchvision are not installed and only decode pixels: empty stand-ins."""
+    import random
+    _stub("lmdb")
+    _stub("cv2", imdecode=lambda buf, flag: np.zeros((2, 2, 3), np.uint8), cvtColor=lambda x, code: x, IMREAD_COLOR=1,
+          COLOR_BGR2RGB=4)
+    tv = _stub("torchvision")
+    tv.datasets = _stub("torchvision.datasets", VisionDataset=object)
+    tv.transforms = _stub("torchvision.transforms")
+    _stub("dataloaders.rawvideo_util", RawVideoExtractor=object)
+    _stub("dataloaders.randaugment", RandomAugment=object)
+    import importlib
+    if not hasattr(np, "long"):
+        np.long = np.int64                     # the reference targets numpy 1.x (dataloader_msrvtt_retrieval.py:297)
+    mod = importlib.import_module("dataloaders.dataloader_msrvtt_retrieval")
+    out = {}
+    for stored in (30, 48):
+        mod.g_lmdb_frames = stored
+        for policy in ("uniform", "random", "uniform_random"):
+            for frames in (7, 12, 24):
+                for seed in (0, 1):
+                    keys = []
+
+                    class Txn:
+                        def get(self, key, _keys=keys):
+                            _keys.append(int(key.decode().rsplit("_", 1)[1]))
+                            return b"\x00" * 8
+                    fake = Namespace(max_frames=frames, frame_sample=policy, _txn=Txn(), resolution=1,
+                                     transform=lambda img: np.zeros((3, 1, 1), np.float32))
+                    random.seed(seed)
+                    mod.MSRVTT_TrainDataLoader._get_rawvideo(fake, ["video0"], frames)
+                    out[f"{policy}.{stored}.{frames}.{seed}"] = np.asarray(keys, dtype=np.int32)
+    save("frame_sampling", **out)
+
+
 def fx_enc_tiny16(mclip, mmodel, mopt, mmetrics):
     _enc_fixture(mclip, mmodel, "enc_tiny16", synth.TINY16, 2, 3, 32, ("fp32", "aswritten"))
 
@@ -436,7 +473,7 @@ def fx_manifest(mclip, mmodel, mopt, mmetrics):
     print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
 
 
-FIXTURES = {"manifest": fx_manifest, "head": fx_head, "enc_tiny": fx_enc_tiny, "enc_rank": fx_enc_rank, "multisent": fx_multisent, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
+FIXTURES = {"manifest": fx_manifest, "head": fx_head, "enc_tiny": fx_enc_tiny, "enc_rank": fx_enc_rank, "multisent": fx_multisent, "frame_sampling": fx_frame_sampling, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
             "bertadam": fx_bertadam, "train_ft": fx_train_ft, "moco": fx_moco}
 
 

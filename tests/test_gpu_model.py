@@ -336,6 +336,33 @@ def test_bertadam_vs_reference_golden():
                     close(mine, ref, 2e-8, 2e-6, f"{name}.{nm}{step}")
 
 
+def test_bertadam_skipped_steps_and_many_groups():
+    """A parameter whose gradient was None for a step has its own step count, hence its own scheduled lr; 40 groups with 40
+    learning rates exceed the 32 hyper-parameter rows of one launch.  Every tensor must still follow
+    modules/optimization.py:103-168 (the oracle's op-by-op restatement), as the reference optimizer would."""
+    from hmmc_amd.optimization import BertAdam
+    n_groups, t_total = 40, 20
+    ps = [torch.nn.Parameter(synth.normal(f"ba2.p{i}", (33 + i,), 0.5).to(DEV)) for i in range(n_groups)]
+    groups = [{"params": [p], "lr": 1e-3 * (1 + i), "weight_decay": 0.1 * (i % 3)} for i, p in enumerate(ps)]
+    opt = BertAdam(groups, lr=1e-3, warmup=0.2, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6, t_total=t_total,
+                   weight_decay=0.0, max_grad_norm=1.0)
+    ref = [(p.detach().cpu().clone(), torch.zeros(p.shape), torch.zeros(p.shape), 0) for p in ps]
+    for step in range(4):
+        for i, p in enumerate(ps):
+            skip = (i == 5 and step == 1) or (i == 17 and step in (0, 2))
+            p.grad = None if skip else synth.normal(f"ba2.g{i}.{step}", tuple(p.shape), 0.3).to(DEV)
+        opt.step()
+        for i, p in enumerate(ps):
+            if p.grad is None:
+                continue
+            rp, rm, rv, rs = ref[i]
+            rp, rm, rv, _ = O.bert_adam_step(rp, p.grad.cpu(), rm, rv, rs, 1e-3 * (1 + i), t_total, 0.2, 0.1 * (i % 3))
+            ref[i] = (rp, rm, rv, rs + 1)
+    for i, p in enumerate(ps):
+        close(p.data, ref[i][0], 1e-7, 2e-6, f"param {i}")
+        assert opt.state[p]["step"] == ref[i][3]
+
+
 def prep_optimizer(model, cfg, t_total):
     from hmmc_amd.optimization import BertAdam
     named = list(model.named_parameters())
@@ -436,6 +463,33 @@ def test_uint8_frames_equal_normalised_fp32_frames():
         out.append((float(loss), model.visual_encoder.visual.conv1.weight.grad.clone()))
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1])
+
+
+def test_frames_sampled_on_the_device_equal_gathered_frames():
+    """The loader's frame sampling (dataloader_msrvtt_retrieval.py:296-312) with the clip's 30 stored uint8 frames in HBM:
+    the encoder reads the sampled frames in place through a device index.  Features equal, bit for bit, those of the same
+    frames gathered and normalised to fp32 on the host first (the reference's path), for all three policies."""
+    import random
+    from hmmc_amd import ops as _ops, sampling
+    model, _ = build(synth.TINY, max_frames=6)
+    model.eval()
+    bs, stored, frames = 3, 30, 6
+    g = torch.Generator().manual_seed(9)
+    clips = torch.randint(0, 256, (bs, stored, 3, 224, 224), generator=g, dtype=torch.uint8)
+    mean = torch.tensor(_ops.CLIP_PIXEL_MEAN).view(1, 1, 3, 1, 1)
+    std = torch.tensor(_ops.CLIP_PIXEL_STD).view(1, 1, 3, 1, 1)
+    clips_dev = clips.to(DEV)
+    for policy in sampling.POLICIES:
+        random.seed(4)
+        index = sampling.batch_frame_index(policy, bs, stored, frames, DEV)
+        random.seed(4)
+        picked = torch.stack([clips[v, sampling.frame_indices(policy, stored, frames)] for v in range(bs)])
+        f32 = (picked.float().div(255.0) - mean) / std
+        with torch.no_grad():
+            v0, u0 = model.visual_encoder(clips_dev, None, frame_index=index)
+            v1, u1 = model.visual_encoder(f32.to(DEV), None)
+        assert u0.shape == (bs, frames, 512)
+        assert torch.equal(u0, u1) and torch.equal(v0, v1), policy
 
 
 def test_step_is_deterministic_across_runs_and_stream_modes():
