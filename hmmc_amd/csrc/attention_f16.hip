@@ -17,10 +17,35 @@
 
 namespace {
 
+constexpr float LOG2E = 1.4426950408889634f;
 
-__device__ __forceinline__ h8 gfrag_clamped(const half_t* src, int row0, int ks, int L, long ld, int lane) {
-  int row = min(row0 + (lane & 15), L - 1);
-  return *reinterpret_cast<const h8*>(src + (long)row * ld + ks * 32 + 8 * (lane >> 4));
+
+// Global -> registers in LANE ORDER: lane l takes row (l >> 3) + 8 i, bytes 16 (l & 7) .. +15 of the [L][64] operand, so
+// every wave-instruction reads 8 full 128-byte rows with consecutive lanes on consecutive bytes.  (Loading the MFMA
+// fragments directly - lane (c, g) on row c, 16 bytes at 64 ks + 16 g - puts 16 consecutive lanes on 16 different rows:
+// the memory pipeline then handles 64 separate 16-byte pieces per instruction; scratch/ubench/burst_store.hip measures
+// 3.4x between the two orders.)  Rows past L are clamped, never masked.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+template <int KT>
+__device__ __forceinline__ void load_rows(const half_t* src, long ld, int L, u4v (&raw)[2 * KT], int lane) {
+#pragma unroll
+  for (int i = 0; i < 2 * KT; ++i) {
+    const int row = min((lane >> 3) + 8 * i, L - 1);
+    raw[i] = *reinterpret_cast<const u4v*>(src + (long)row * ld + 8 * (lane & 7));
+  }
+}
+// ... -> the wave's LDS tile (row-major, LDS_STRIDE) -> MFMA row fragments f[t][ks] = rows 16 t + (lane & 15), halves
+// 32 ks + 8 (lane >> 4) .. +7.  The tile keeps the operand afterwards (the transposed reads use it).
+template <int KT>
+__device__ __forceinline__ void rows_to_frags(half_t* tile, const u4v (&raw)[2 * KT], h8 (&f)[KT][2], int lane) {
+#pragma unroll
+  for (int i = 0; i < 2 * KT; ++i)
+    *reinterpret_cast<u4v*>(tile + ((lane >> 3) + 8 * i) * LDS_STRIDE + 8 * (lane & 7)) = raw[i];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      f[t][ks] = *reinterpret_cast<const h8*>(tile + (t * 16 + (lane & 15)) * LDS_STRIDE + ks * 32 + 8 * (lane >> 4));
 }
 
 // store the wave's [LP][64] operand (row fragments in registers) into its LDS tile, row-major
@@ -33,30 +58,24 @@ __device__ __forceinline__ void frags_to_tile(half_t* tile, const h8 (&f)[KT][2]
       *reinterpret_cast<h8*>(tile + (t * 16 + (lane & 15)) * LDS_STRIDE + ks * 32 + 8 * (lane >> 4)) = f[t][ks];
 }
 
-// X^T[d-tile dt][d = dt*16 + 4g + r][row = 16j + c] accumulators (4 d-tiles) -> global [row][64], 16 B per lane
-template <int KT>
-__device__ __forceinline__ void store_t(half_t* dst, long ld, const f4 (&acc)[4], int row, bool ok, int lane) {
-  const int g = lane >> 4;
-  unsigned d[4][2];
+// X^T[d = dt*16 + 4g + r][row = c] accumulators (4 d-tiles) of the 16 rows row0 .. row0 + 15 -> global [row][64].  The
+// strip goes through a 16 x 144 B LDS scratch (8-byte writes from the MFMA layout, 16-byte reads in lane order) so that
+// every store instruction writes 8 full 128-byte rows with consecutive lanes on consecutive bytes; a wave's LDS
+// operations execute in order, so strips follow each other without a wait.
+__device__ __forceinline__ void store_rows(half_t* dst, long ld, const f4 (&acc)[4], int row0, int L, half_t* scr, int lane) {
+  const int g = lane >> 4, c = lane & 15;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     h4 v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = (half_t)acc[dt][r];
-    typedef unsigned u2v __attribute__((ext_vector_type(2)));
-    u2v u = __builtin_bit_cast(u2v, v);
-    d[dt][0] = u[0]; d[dt][1] = u[1];
+    *reinterpret_cast<h4*>(scr + c * LDS_STRIDE + dt * 16 + 4 * g) = v;
   }
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      auto r = __builtin_amdgcn_permlane16_swap(d[2 * q][e], d[2 * q + 1][e], false, false);
-      d[2 * q][e] = r[0]; d[2 * q + 1][e] = r[1];
-    }
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    u4v o = {d[2 * q][0], d[2 * q][1], d[2 * q + 1][0], d[2 * q + 1][1]};
-    if (ok) *reinterpret_cast<u4v*>(dst + (long)row * ld + 32 * q + 16 * (g & 1) + 8 * (g >> 1)) = o;
+  for (int t = 0; t < 2; ++t) {
+    const int r = (lane >> 3) + 8 * t;
+    const u4v o = *reinterpret_cast<const u4v*>(scr + r * LDS_STRIDE + 8 * (lane & 7));
+    if (row0 + r < L) *reinterpret_cast<u4v*>(dst + (long)(row0 + r) * ld + 8 * (lane & 7)) = o;
   }
 }
 
@@ -74,23 +93,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
   const half_t* q = p.qkv + (long)n * L * ld + h * DH;
   const half_t* k = q + D;
   const half_t* v = q + 2 * D;
-  half_t* vtile = reinterpret_cast<half_t*>(smem) + wid * (LP * LDS_STRIDE);
+  half_t* vtile = reinterpret_cast<half_t*>(smem) + wid * (LP * LDS_STRIDE + 16 * LDS_STRIDE);
+  half_t* scr = vtile + LP * LDS_STRIDE;
   const int g = lane >> 4, c = lane & 15;
 
-  // every operand is requested before the first MFMA (rows past L clamped; masked below where it matters)
+  // every operand is requested before the first MFMA (rows past L clamped; masked below where it matters); V goes last
+  // through the tile, which then holds it for the transposed reads
   h8 kf[KT][2], qf[KT][2], vf[KT][2];
-#pragma unroll
-  for (int t = 0; t < KT; ++t)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      kf[t][ks] = gfrag_clamped(k, t * 16, ks, L, ld, lane);
-      qf[t][ks] = gfrag_clamped(q, t * 16, ks, L, ld, lane);
-    }
-#pragma unroll
-  for (int t = 0; t < KT; ++t)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) vf[t][ks] = gfrag_clamped(v, t * 16, ks, L, ld, lane);
-  frags_to_tile<KT>(vtile, vf, lane);
+  {
+    u4v rk[2 * KT], rq[2 * KT], rv[2 * KT];
+    load_rows<KT>(k, ld, L, rk, lane);
+    load_rows<KT>(q, ld, L, rq, lane);
+    load_rows<KT>(v, ld, L, rv, lane);
+    rows_to_frags<KT>(vtile, rk, kf, lane);
+    rows_to_frags<KT>(vtile, rq, qf, lane);
+    rows_to_frags<KT>(vtile, rv, vf, lane);
+  }
   h8 vT[4][KT / 2];                              // V^T fragments, k-order permuted like the P^T accumulators
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
       for (int ks = 0; ks < KT / 2; ++ks)
         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vT[dt][ks], cat4(pt[2 * ks], pt[2 * ks + 1]), acc[dt], 0, 0, 0);
     }
-    store_t<KT>(o, D, acc, qi, qi < L, lane);
+    store_rows(o, D, acc, qt * 16, L, scr, lane);
   }
 }
 
@@ -195,7 +213,7 @@ __device__ __forceinline__ void store_colsum(float* dst, f4 (&csum)[4], int lane
 template <int KT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = 16 * KT;
-  constexpr int WAVE_LDS = LP * LDS_STRIDE * 2 + 2 * LP * 4;     // tile + lse[LP] + delta[LP]
+  constexpr int WAVE_LDS = LP * LDS_STRIDE * 2 + 16 * LDS_STRIDE * 2 + 2 * LP * 4;     // tile + store scratch + lse[LP] + delta[LP]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -212,38 +230,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   half_t* dk = dq + D;
   half_t* dv = dq + 2 * D;
   half_t* xt = reinterpret_cast<half_t*>(smem + wid * WAVE_LDS);
-  float* lse_s = reinterpret_cast<float*>(smem + wid * WAVE_LDS + LP * LDS_STRIDE * 2);
+  half_t* scr = xt + LP * LDS_STRIDE;
+  float* lse_s = reinterpret_cast<float*>(smem + wid * WAVE_LDS + LP * LDS_STRIDE * 2 + 16 * LDS_STRIDE * 2);
   float* del_s = lse_s + LP;
   const int g = lane >> 4, c = lane & 15;
   const float* lse_g = p.lse + ((long)n * p.H + h) * L;
 
   h8 qf[KT][2], kf[KT][2], vf[KT][2], df[KT][2];
-#pragma unroll
-  for (int t = 0; t < KT; ++t)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      kf[t][ks] = gfrag_clamped(k, t * 16, ks, L, ld, lane);
-      qf[t][ks] = gfrag_clamped(q, t * 16, ks, L, ld, lane);
-    }
-#pragma unroll
-  for (int t = 0; t < KT; ++t)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      vf[t][ks] = gfrag_clamped(v, t * 16, ks, L, ld, lane);
-      df[t][ks] = gfrag_clamped(dO, t * 16, ks, L, D, lane);
-    }
+  {
+    u4v rq[2 * KT], rk[2 * KT], rv[2 * KT], rd[2 * KT];
+    load_rows<KT>(q, ld, L, rq, lane);
+    load_rows<KT>(v, ld, L, rv, lane);
+    load_rows<KT>(dO, D, L, rd, lane);
+    load_rows<KT>(k, ld, L, rk, lane);
+    rows_to_frags<KT>(xt, rq, qf, lane);
+    rows_to_frags<KT>(xt, rv, vf, lane);
+    rows_to_frags<KT>(xt, rd, df, lane);
+    rows_to_frags<KT>(xt, rk, kf, lane);       // K last: phase 1 reads K^T from the tile
+  }
   float lse_c[KT];                               // lse of query qt*16 + c; +inf past L: its probabilities vanish
 #pragma unroll
   for (int t = 0; t < KT; ++t) lse_c[t] = (t * 16 + c < L) ? lse_g[t * 16 + c] : INFINITY;
-  if (g == 0) {
+  if (g == 0) {                                  // exp(x - lse) = exp2(x log2(e) - lse log2(e)): one fma + v_exp_f32 per probability
 #pragma unroll
-    for (int t = 0; t < KT; ++t) lse_s[t * 16 + c] = lse_c[t];
+    for (int t = 0; t < KT; ++t) lse_s[t * 16 + c] = LOG2E * lse_c[t];
   }
 
   float* dbias = p.dbias ? p.dbias + (long)n * 3 * D + h * DH : nullptr;   // + type * D
   f4 csum[4];
-  // ---- phase 1: keys on the lane's rows -> delta and dQ
-  frags_to_tile<KT>(xt, kf, lane);
+  // ---- phase 1: keys on the lane's rows -> delta and dQ (the tile holds K)
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) csum[dt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + 4 * g + r;
-        float pv = __expf(s[kt][r] * 0.125f - lse_c[qt]);
+        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], 0.125f * LOG2E, -LOG2E * lse_c[qt]));
         if ((kt + 1) * 16 > L || p.causal) pv = (key < L && (!p.causal || key <= qi)) ? pv : 0.f;
         s[kt][r] = pv;
         dl += pv * dp[kt][r];
@@ -286,65 +301,57 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane),
                                                          cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[dt], 0, 0, 0);
     }
-    store_t<KT>(dq, ld, acc, qi, qi < L, lane);
+    store_rows(dq, ld, acc, qt * 16, L, scr, lane);
     if (dbias) add_rounded(csum, acc);           // rows past L are exact zeros (their dS is)
   }
   if (dbias) store_colsum(dbias, csum, lane);
 
-  // ---- phase 2a: queries on the lane's rows -> P and dS as B operands of dV / dK
-  h4 p16[KT][KT], ds16[KT][KT];                  // [kt][qt]
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    const int key = kt * 16 + c;
-    f4 s[KT], dp[KT];
-#pragma unroll
-    for (int qt = 0; qt < KT; ++qt) {
-      f4 z = {0.f, 0.f, 0.f, 0.f};
-      s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qt][0], kf[kt][0], z, 0, 0, 0);
-      s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qt][1], kf[kt][1], s[qt], 0, 0, 0);
-      dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[qt][0], vf[kt][0], z, 0, 0, 0);
-      dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[qt][1], vf[kt][1], dp[qt], 0, 0, 0);
-    }
-#pragma unroll
-    for (int qt = 0; qt < KT; ++qt) {
-      const f4 lr = *reinterpret_cast<const f4*>(lse_s + qt * 16 + 4 * g);
-      const f4 dr = *reinterpret_cast<const f4*>(del_s + qt * 16 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qi = qt * 16 + 4 * g + r;
-        float pv = __expf(s[qt][r] * 0.125f - lr[r]);
-        if ((kt + 1) * 16 > L || p.causal) pv = (key < L && (!p.causal || key <= qi)) ? pv : 0.f;
-        p16[kt][qt][r] = (half_t)pv;
-        ds16[kt][qt][r] = (half_t)(pv * (dp[qt][r] - dr[r]) * 0.125f);
-      }
-    }
-  }
-  // ---- phase 2b: dV^T[d][key] = sum_q dO[q][d] P[q][key];  dK^T[d][key] = sum_q Q[q][d] dS[q][key]
+  // ---- phase 2: queries on the lane's rows.  dV^T[d][key] = sum_q dO[q][d] P[q][key], then dK^T[d][key] = sum_q Q[q][d]
+  // dS[q][key].  One key tile at a time and the probabilities formed again in each pass (32 MFMAs and 64 exponentials
+  // more): P or dS of ONE key tile (8 VGPRs) is all that lives beside the four operand fragments.  Holding P and dS of all
+  // 16 tile pairs (64 VGPRs) as the B operands of both products took the kernel to 286 VGPRs: 30 spilled to scratch
+  // memory and reloaded behind full vmcnt waits in the middle of the MFMA stream.
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 0) frags_to_tile<KT>(xt, df, lane); else frags_to_tile<KT>(xt, qf, lane);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) csum[dt] = f4{0.f, 0.f, 0.f, 0.f};
-    h8 xT[4][KT / 2];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int ks = 0; ks < KT / 2; ++ks) xT[dt][ks] = tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane);
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
+      const int key = kt * 16 + c;
+      h4 b16[KT];                                // P (pass 0) or dS (pass 1) of key tile kt, [qt]
+#pragma unroll
+      for (int qt = 0; qt < KT; ++qt) {
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+        f4 sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qt][0], kf[kt][0], z, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qt][1], kf[kt][1], sc, 0, 0, 0);
+        f4 dp = z;
+        if (pass == 1) {
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[qt][0], vf[kt][0], z, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[qt][1], vf[kt][1], dp, 0, 0, 0);
+        }
+        const f4 lr = *reinterpret_cast<const f4*>(lse_s + qt * 16 + 4 * g);
+        const f4 dr = *reinterpret_cast<const f4*>(del_s + qt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = qt * 16 + 4 * g + r;
+          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], 0.125f * LOG2E, -lr[r]));      // lse_s holds lse * log2(e)
+          if ((kt + 1) * 16 > L || p.causal) pv = (key < L && (!p.causal || key <= qi)) ? pv : 0.f;
+          b16[qt][r] = pass == 0 ? (half_t)pv : (half_t)(pv * (dp[r] - dr[r]) * 0.125f);
+        }
+      }
       f4 acc[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KT / 2; ++ks) {
-          h8 bfrag = pass == 0 ? cat4(p16[kt][2 * ks], p16[kt][2 * ks + 1]) : cat4(ds16[kt][2 * ks], ds16[kt][2 * ks + 1]);
-          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xT[dt][ks], bfrag, acc[dt], 0, 0, 0);
-        }
+        for (int ks = 0; ks < KT / 2; ++ks)        // dO^T / Q^T fragments re-read from the tile
+          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane),
+                                                           cat4(b16[2 * ks], b16[2 * ks + 1]), acc[dt], 0, 0, 0);
       }
-      const int key = kt * 16 + c;
-      store_t<KT>(pass == 0 ? dv : dk, ld, acc, key, key < L, lane);
+      store_rows(pass == 0 ? dv : dk, ld, acc, kt * 16, L, scr, lane);
       if (dbias) add_rounded(csum, acc);         // keys past L are exact zeros (P and dS are)
+      __builtin_amdgcn_sched_barrier(0);         // one key tile at a time: the scheduler would otherwise hoist every tile's MFMAs
     }
     if (dbias) store_colsum(dbias + (pass == 0 ? 2 : 1) * D, csum, lane);
   }
@@ -368,8 +375,8 @@ extern "C" int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, in
   p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = lse; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   long pairs = (long)nseq * H;
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
-  if (L <= 32) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, 4 * 32 * LDS_STRIDE * 2, stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, 4 * 64 * LDS_STRIDE * 2, stream, p);
+  if (L <= 32) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, 4 * (32 + 16) * LDS_STRIDE * 2, stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, 4 * (64 + 16) * LDS_STRIDE * 2, stream, p);
   return hmmc_launch_status();
 }
 
@@ -389,7 +396,7 @@ extern "C" int hmmc_attention_f16_bwd(const void* qkv, const void* out, const fl
   p.dqkv = (half_t*)dqkv; p.dbias = dbias_partial; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   long pairs = (long)nseq * H;
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
-  if (L <= 32) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, 4 * (32 * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);
-  else hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, block, 4 * (64 * LDS_STRIDE * 2 + 2 * 64 * 4), stream, p);
+  if (L <= 32) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, 4 * ((32 + 16) * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);
+  else hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, block, 4 * ((64 + 16) * LDS_STRIDE * 2 + 2 * 64 * 4), stream, p);
   return hmmc_launch_status();
 }

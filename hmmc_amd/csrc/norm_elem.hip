@@ -15,7 +15,11 @@ template <> struct Vec<float> { static constexpr int N = 4; typedef f4 type; };
 
 constexpr int LN_MAXD = 1024;  // widest LayerNorm row (ViT-B: 768, text/temporal: 512)
 
-// ---- LayerNorm forward: one wave per row ------------------------------------------------------
+// ---- LayerNorm forward ------------------------------------------------------------------------------------------------
+// A wave owns rows w, w + nwaves, ...: gamma and beta stay in registers for all of them, the next row is requested before
+// the current one is reduced (two dependent wave reductions sit between a row's load and its store), and every load is
+// unconditional - a lane whose chunk lies past the row's end re-reads chunk 0 and its values are masked out - because a
+// branch around a load makes the compiler wait for every load in flight where the paths join.
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
@@ -26,47 +30,54 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   constexpr int LN_MAXV = LN_MAXD / 64 / VN;
   typedef typename Vec<T>::type V;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const long src_row = row_index ? (long)row_index[row] : (long)row;
-  const T* xr = x + src_row * in_stride;
+  const int nwaves = gridDim.x * 4;
   const int nchunk = D / VN;
-  float v[LN_MAXV][VN];
-  float s = 0.f;
+  bool ok[LN_MAXV];
+  int ce[LN_MAXV];
+  float gm[LN_MAXV][VN], bt[LN_MAXV][VN];
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
-    int c = lane + 64 * i;
-    if (c < nchunk) {
-      V t = *reinterpret_cast<const V*>(xr + c * VN);
+    ok[i] = lane + 64 * i < nchunk;
+    ce[i] = ok[i] ? (lane + 64 * i) * VN : 0;
 #pragma unroll
-      for (int j = 0; j < VN; ++j) { v[i][j] = (float)t[j]; s += v[i][j]; }
-    }
+    for (int j = 0; j < VN; ++j) { gm[i][j] = gamma[ce[i] + j]; bt[i][j] = beta[ce[i] + j]; }
   }
-  const float mean = wave_sum(s) / D;
-  float q = 0.f;
+  auto load_row = [&](int row, V (&t)[LN_MAXV]) {
+    const long src_row = row_index ? (long)row_index[row] : (long)row;
+    const T* xr = x + src_row * in_stride;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    int c = lane + 64 * i;
-    if (c < nchunk) {
+    for (int i = 0; i < LN_MAXV; ++i) t[i] = *reinterpret_cast<const V*>(xr + ce[i]);
+  };
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  V cur[LN_MAXV], nxt[LN_MAXV];
+  load_row(row, cur);
+  for (; row < rows; row += nwaves) {
+    load_row(min(row + nwaves, rows - 1), nxt);          // past the last row: a harmless re-read
+    float v[LN_MAXV][VN];
+    float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < VN; ++j) { float d = v[i][j] - mean; q += d * d; }
-    }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
-  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-  T* yr = y + (long)row * D;
+    for (int i = 0; i < LN_MAXV; ++i)
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    int c = lane + 64 * i;
-    if (c < nchunk) {
+      for (int j = 0; j < VN; ++j) { v[i][j] = (float)cur[i][j]; if (ok[i]) s += v[i][j]; }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+      for (int j = 0; j < VN; ++j) { float d = v[i][j] - mean; if (ok[i]) q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    T* yr = y + (long)row * D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
       V o;
 #pragma unroll
-      for (int j = 0; j < VN; ++j) {
-        int col = c * VN + j;
-        o[j] = (T)((v[i][j] - mean) * rstd * gamma[col] + beta[col]);
-      }
-      *reinterpret_cast<V*>(yr + c * VN) = o;
+      for (int j = 0; j < VN; ++j) o[j] = (T)((v[i][j] - mean) * rstd * gm[i][j] + bt[i][j]);
+      if (ok[i]) *reinterpret_cast<V*>(yr + ce[i]) = o;
     }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) cur[i] = nxt[i];
   }
 }
 
@@ -74,8 +85,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.
 // Rows are read through the same optional row_index / in_stride as the forward; dx rows are
 // written to dx + dst_row * out_stride where dst_row = row_index ? row_index[row] : row.
+// Same structure as the forward: gamma in registers, the next row's x / dy / residual gradient requested before this row's
+// two reductions, unconditional loads.
 template <typename T>
-__global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256, 3) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ partial,
@@ -87,32 +100,54 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy
   __shared__ float sred[4 * LN_MAXD];   // one stripe per wave
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nchunk = D / VN;
+  const int nwaves = gridDim.x * 4;
+  bool ok[LN_MAXV];
+  int ce[LN_MAXV];
+  float gm[LN_MAXV][VN];
   float dg[LN_MAXV][VN], db[LN_MAXV][VN], ds[LN_MAXV][VN];   // ds: column sums of the dx rows written (bias gradient
 #pragma unroll                                                //     of the linear layer that produced this activation)
-  for (int i = 0; i < LN_MAXV; ++i)
+  for (int i = 0; i < LN_MAXV; ++i) {
+    ok[i] = lane + 64 * i < nchunk;
+    ce[i] = ok[i] ? (lane + 64 * i) * VN : 0;
 #pragma unroll
-    for (int j = 0; j < VN; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; ds[i][j] = 0.f; }
-
-  for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+    for (int j = 0; j < VN; ++j) { gm[i][j] = gamma[ce[i] + j]; dg[i][j] = 0.f; db[i][j] = 0.f; ds[i][j] = 0.f; }
+  }
+  const bool has_res = dres != nullptr;
+  auto load_row = [&](int row, V (&tx)[LN_MAXV], V (&td)[LN_MAXV], float& mean, float& rstd) {
     const long src_row = row_index ? (long)row_index[row] : (long)row;
     const T* xr = x + src_row * in_stride;
     const T* dyr = dy + (long)row * D;
-    const float mean = mean_in[row], rstd = rstd_in[row];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      tx[i] = *reinterpret_cast<const V*>(xr + ce[i]);
+      td[i] = *reinterpret_cast<const V*>(dyr + ce[i]);
+    }
+    mean = mean_in[row];
+    rstd = rstd_in[row];
+  };
+  int row = blockIdx.x * 4 + w;
+  V tx[LN_MAXV], td[LN_MAXV], tr[LN_MAXV], nx[LN_MAXV], nd[LN_MAXV];
+  float mean = 0.f, rstd = 0.f, nmean, nrstd;
+  if (row < rows) load_row(row, tx, td, mean, rstd);
+  for (; row < rows; row += nwaves) {
+    const long src_row = row_index ? (long)row_index[row] : (long)row;
+    // this row's residual gradient (used after the two reductions below) and the next row's x / dy
+    if (has_res) {
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) tr[i] = *reinterpret_cast<const V*>(dres + src_row * in_stride + ce[i]);
+    }
+    load_row(min(row + nwaves, rows - 1), nx, nd, nmean, nrstd);
     // the row stays in registers as loaded (packed); xhat and g are recomputed for the second sweep instead of
-    // being held as fp32 arrays: 16 VGPRs instead of 32 for a half row, which keeps 4 waves per SIMD resident
-    V tx[LN_MAXV], td[LN_MAXV];
+    // being held as fp32 arrays, which keeps 4 waves per SIMD resident
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
-      int c = lane + 64 * i;
-      if (c < nchunk) {
-        tx[i] = *reinterpret_cast<const V*>(xr + c * VN);
-        td[i] = *reinterpret_cast<const V*>(dyr + c * VN);
+      if (ok[i]) {
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
           float d = (float)td[i][j];
           float xh = ((float)tx[i][j] - mean) * rstd;
-          float g = d * gamma[c * VN + j];
+          float g = d * gm[i][j];
           s1 += g;
           s2 += g * xh;
           dg[i][j] += d * xh;
@@ -123,26 +158,23 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy
     s1 = wave_sum(s1) / D;
     s2 = wave_sum(s2) / D;
     T* dxr = dx + src_row * in_stride;
-    const T* drr = dres ? dres + src_row * in_stride : nullptr;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
-      int c = lane + 64 * i;
-      if (c < nchunk) {
-        V o;
-        V rr;
-        if (drr) rr = *reinterpret_cast<const V*>(drr + c * VN);
+      V o;
 #pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          float xh = ((float)tx[i][j] - mean) * rstd;
-          float g = (float)td[i][j] * gamma[c * VN + j];
-          float val = rstd * (g - s1 - xh * s2);
-          if (drr) val += (float)rr[j];
-          o[j] = (T)val;
-          ds[i][j] += (float)o[j];
-        }
-        *reinterpret_cast<V*>(dxr + c * VN) = o;
+      for (int j = 0; j < VN; ++j) {
+        float xh = ((float)tx[i][j] - mean) * rstd;
+        float g = (float)td[i][j] * gm[i][j];
+        float val = rstd * (g - s1 - xh * s2);
+        if (has_res) val += (float)tr[i][j];
+        o[j] = (T)val;
+        if (ok[i]) ds[i][j] += (float)o[j];
       }
+      if (ok[i]) *reinterpret_cast<V*>(dxr + ce[i]) = o;
     }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) { tx[i] = nx[i]; td[i] = nd[i]; }
+    mean = nmean; rstd = nrstd;
   }
   // combine the 4 waves of the block, then one partial row per block: partial[block][0|1|2][D]
   const int npass = want_dxsum ? 3 : 2;
@@ -150,10 +182,9 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
-      int c = lane + 64 * i;
-      if (c < nchunk) {
+      if (ok[i]) {
 #pragma unroll
-        for (int j = 0; j < VN; ++j) sred[w * LN_MAXD + c * VN + j] = pass == 0 ? dg[i][j] : (pass == 1 ? db[i][j] : ds[i][j]);
+        for (int j = 0; j < VN; ++j) sred[w * LN_MAXD + ce[i] + j] = pass == 0 ? dg[i][j] : (pass == 1 ? db[i][j] : ds[i][j]);
       }
     }
     __syncthreads();
@@ -478,7 +509,11 @@ extern "C" int hmmc_layernorm_fwd(const void* x, const float* gamma, const float
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return HMMC_ERR_ARG;
   int vn = dtype == 0 ? 8 : 4;
   if (D % vn || D > LN_MAXD || in_stride % vn) return HMMC_ERR_UNSUPPORTED;
-  dim3 grid((rows + 3) / 4), block(256);
+  // 8 rows per wave at least (gamma / beta are loaded once per wave), at most 8 workgroups per CU
+  int nb = (rows + 31) / 32;
+  const int cap = hmmc_num_cus() * 8;
+  if (nb > cap) nb = cap;
+  dim3 grid(nb < 1 ? 1 : nb), block(256);
   if (dtype == 0)
     hipLaunchKernelGGL(ln_fwd_kernel<half_t>, grid, block, 0, stream, (const half_t*)x, gamma, beta, (half_t*)y, mean, rstd,
                        row_index, rows, D, in_stride, eps);
@@ -489,10 +524,13 @@ extern "C" int hmmc_layernorm_fwd(const void* x, const float* gamma, const float
 }
 
 // blocks of the LayerNorm backward = rows of its partial matrix: 8 rows per wave at least (the second-stage reduce reads
-// nb x 3D floats, which at a few thousand rows would otherwise cost as much as the backward itself), 1024 blocks at most
+// nb x 3D floats, which at a few thousand rows would otherwise cost as much as the backward itself), and no more blocks
+// than are resident at once (a second, partial round of blocks would leave most CUs idle at the end)
+constexpr int LN_BWD_BLOCKS_PER_CU = 3;      // = the second __launch_bounds__ argument of ln_bwd_kernel: one resident round
 static inline int ln_bwd_blocks(int rows) {
   int nb = (rows + 31) / 32;
-  if (nb > 1024) nb = 1024;
+  const int cap = hmmc_num_cus() * LN_BWD_BLOCKS_PER_CU;
+  if (nb > cap) nb = cap;
   return nb < 1 ? 1 : nb;
 }
 
