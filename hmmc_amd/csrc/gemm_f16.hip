@@ -169,12 +169,19 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
   const int flags = F >= 0 ? (F & ~EPI_COLSUM) : (p.flags & ~EPI_COLSUM);
   const bool want_csum = F >= 0 ? (F & EPI_COLSUM) != 0 : p.csum != nullptr;
   const int c = lane & 15, g = lane >> 4;
-  // MFMA side of the LDS tile: piece j of this lane at mf_off ^ (32 j)
+  // MFMA side of the LDS tiles: piece j of this lane at mf_off ^ (32 j).  Two layouts, because the two directions use
+  // different instructions: the operand tile is READ with ds_read_b64 (32-lane groups, 64 banks: rows c and c + 8 must
+  // differ in their chunk -> key(c) = (c & 7) ^ (c >> 3)); the result tile is WRITTEN with ds_write_b64 (16-lane groups, 32
+  // banks: the 16 rows of a group must cover both 8-byte halves of 8 chunks -> chunk ^ (c & 7), half ^ (c >> 3); measured
+  // with the operand layout: SQ_LDS_BANK_CONFLICT 8.7 % of the LDS cycles of the launch).  The line side swaps the two
+  // halves of the pieces of rows 8..15 to match.
   const int mf_off = c * 128 + (((g >> 1) ^ ((c & 7) ^ (c >> 3))) << 4) + 8 * (g & 1);
+  const int mf_out = c * 128 + (((g >> 1) ^ (c & 7)) << 4) + 8 * ((g & 1) ^ (c >> 3));
   // line side: lane l reads / writes row (l >> 3) + 8 t, chunk l & 7
   const int r_l = lane >> 3, q_l = lane & 7;
-  const int ln_off0 = r_l * 128 + ((q_l ^ r_l) << 4);                  // key(r_l) = r_l for rows 0..7
-  const int ln_off1 = (r_l + 8) * 128 + ((q_l ^ r_l ^ 1) << 4);        // key(r_l + 8) = r_l ^ 1
+  const int ln_off0 = r_l * 128 + ((q_l ^ r_l) << 4);                  // both layouts: key = r_l for rows 0..7
+  const int ln_off1 = (r_l + 8) * 128 + ((q_l ^ r_l ^ 1) << 4);        // operand tile: key(r_l + 8) = r_l ^ 1
+  const int ln_out1 = (r_l + 8) * 128 + ((q_l ^ r_l) << 4);            // result tile: same chunk, halves swapped
   const bool n_ok = FULL || n0 + 8 * q_l < p.N;                        // N % 8 == 0: a 16-byte piece is all-in or all-out
   // global address = uniform 64-bit base (scalar registers) + 32-bit lane offset
   const unsigned voff = ((unsigned)r_l * (unsigned)p.ldc + (unsigned)(8 * q_l)) * 2u;
@@ -237,9 +244,10 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
   };
   auto store_strip = [&](half_t* dst, int i, const u2 (&pc)[4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<u2*>(scr + (mf_off ^ (32 * j))) = pc[j];
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<u2*>(scr + (mf_out ^ (32 * j))) = pc[j];
     const u4 o0 = *reinterpret_cast<const u4*>(scr + ln_off0);
-    const u4 o1 = *reinterpret_cast<const u4*>(scr + ln_off1);
+    const u4 t1 = *reinterpret_cast<const u4*>(scr + ln_out1);
+    const u4 o1 = u4{t1[2], t1[3], t1[0], t1[1]};
     flush();
     pv0 = o0; pv1 = o1; pv_dst = dst; pv_i = i; have_prev = true;
   };

@@ -17,7 +17,7 @@ for name, lay, M, N, K, epi in shapes:
     kw = {}
     if "b" in epi: kw["bias"] = torch.randn(N, device="cuda", generator=g).half()
     if "r" in epi: kw["resid"] = torch.randn(M, N, device="cuda", generator=g).half()
-    new = hasattr(ops, "EPI_MULAUX") and not os.environ.get("HMMC_LIB")
+    new = hasattr(ops, "EPI_MULAUX")
     if "g" in epi: kw.update(epilogue=ops.EPI_QGELU | (ops.EPI_SAVE_DGELU if new else 0), want_aux=True)
     if "d" in epi: kw.update(epilogue=ops.EPI_MULAUX if new else ops.EPI_DGELU, aux_in=torch.randn(M, N, device="cuda", generator=g).half(), want_colsum=True)
     if lay == "kk":
