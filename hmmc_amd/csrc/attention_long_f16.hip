@@ -46,116 +46,131 @@ __device__ __forceinline__ void store_row16(half_t* dst, long ld, const f4 (&acc
   }
 }
 
-// Forward: one wave per (sequence, head, 64-query block), online softmax over 64-key blocks.  Q, K and V rows go from
-// global memory straight into MFMA fragments; only V passes through the wave's LDS tile (transposed reads for O^T = V^T P^T),
-// so a workgroup of four waves needs 36 KiB and two waves per SIMD stay resident.
+// Forward: one WORKGROUP per (sequence, head).  Its four waves first bring the head's K and V (all L <= 256 keys: 2 x 36 KiB
+// at most) into LDS with full-row, lane-ordered loads, once; then each wave takes 16-query tiles (tile w, w + 4, ...).  A
+// whole row of scores - KTL key tiles x 4 values per lane - fits the registers, so the softmax is the one-block kernel's
+// (attention_f16.hip: in-register maximum and sum, two 16-lane shuffles, no online rescaling), K fragments come from LDS with
+// ds_read_b128 and V^T fragments with ds_read_b64_tr_b16.  Against the previous wave-private 64 x 64 blocks (each wave
+// fetching every K / V block itself, in 16-byte pieces, with nothing in flight while it computed) this reads K and V once
+// per head instead of four times and has no global load between the first MFMA and the last.
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int KTL, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_long_fwd_kernel(AttnArgs p) {
+  constexpr int ROWS = 16 * KTL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nqb = (p.L + 63) / 64;
-  const long idx = (long)blockIdx.x * 4 + wid;
-  if (idx >= (long)p.nseq * p.H * nqb) return;
-  const int qb = (int)(idx % nqb);
-  const long pair = idx / nqb;
-  const int n = (int)(pair / p.H), h = (int)(pair % p.H);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int D = p.H * DH, L = p.L;
   const long ld = 3L * D;
   const half_t* q = p.qkv + (long)n * L * ld + h * DH;
   const half_t* k = q + D;
   const half_t* v = q + 2 * D;
-  half_t* vtile = reinterpret_cast<half_t*>(smem) + wid * (64 * LDS_STRIDE);
+  half_t* ktile = reinterpret_cast<half_t*>(smem);
+  half_t* vtile = ktile + ROWS * LDS_STRIDE;
+  half_t* scr = vtile + ROWS * LDS_STRIDE + wid * (16 * LDS_STRIDE);
   const int g = lane >> 4, c = lane & 15;
-  const int q0 = qb * 64;
-  h8 qf[4][2];
+  {                                              // K, V -> LDS: thread -> row (tid >> 3) + 32 i, bytes 16 (tid & 7) .. +15; rows past L zero
+    u4v rk[ROWS / 32], rv[ROWS / 32];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const long off = (long)min(row, L - 1) * ld + 8 * (tid & 7);
+      rk[i] = *reinterpret_cast<const u4v*>(k + off);
+      rv[i] = *reinterpret_cast<const u4v*>(v + off);
+    }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[t][ks] = gfrag_clamped(q, q0 + t * 16, ks, L, ld, lane);
-  float m[4], l[4];
-  f4 acc[4][4];                                  // [d-tile][query tile]
-#pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    m[qt] = -INFINITY; l[qt] = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt][qt] = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  const int nkb = p.causal ? qb + 1 : nqb;
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int k0 = kb * 64;
-    h8 kf[4][2], vf[4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        kf[t][ks] = gfrag_clamped(k, k0 + t * 16, ks, L, ld, lane);
-        vf[t][ks] = gfrag_clamped(v, k0 + t * 16, ks, L, ld, lane);
-      }
-    frags_to_tile(vtile, vf, lane);
-    h8 vT[4][2];                                 // V^T fragments, k-order permuted like the P^T accumulators
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) vT[dt][ks] = tr_frag(vtile, ks * 32, ks * 32 + 16, dt * 16, lane);
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      const int qi = q0 + qt * 16 + c;
-      f4 s[4];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        f4 z = {0.f, 0.f, 0.f, 0.f};
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][0], qf[qt][0], z, 0, 0, 0);
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][1], qf[qt][1], s[kt], 0, 0, 0);
-      }
-      float bm = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = k0 + kt * 16 + 4 * g + r;
-          const bool ok = key < L && (!p.causal || key <= qi || qi >= L);
-          const float val = ok ? s[kt][r] * 0.125f : -INFINITY;
-          s[kt][r] = val;
-          bm = fmaxf(bm, val);
-        }
-      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-      const float mn = fmaxf(m[qt], bm);
-      const float alpha = (mn == -INFINITY) ? 1.f : __expf(m[qt] - mn);
-      float sum = 0.f;
-      h4 pt[4];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = (mn == -INFINITY) ? 0.f : __expf(s[kt][r] - mn);
-          pt[kt][r] = (half_t)e;
-          sum += e;
-        }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      l[qt] = l[qt] * alpha + sum;
-      m[qt] = mn;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        f4 a = acc[dt][qt] * alpha;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_f16(vT[dt][ks], cat4(pt[2 * ks], pt[2 * ks + 1]), a, 0, 0, 0);
-        acc[dt][qt] = a;
-      }
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const u4v z = {0u, 0u, 0u, 0u};
+      *reinterpret_cast<u4v*>(ktile + row * LDS_STRIDE + 8 * (tid & 7)) = row < L ? rk[i] : z;
+      *reinterpret_cast<u4v*>(vtile + row * LDS_STRIDE + 8 * (tid & 7)) = row < L ? rv[i] : z;
     }
   }
+  __syncthreads();
   half_t* o = p.out + (long)n * L * D + h * DH;
+  const int nqt = (L + 15) / 16;
+  // a tile's 16 query rows: lane-ordered loads (requested one tile ahead) -> scratch -> row fragments
+  auto load_q = [&](int qt, u4v (&raw)[2]) {
 #pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    const int qi = q0 + qt * 16 + c;
-    const float inv = 1.0f / l[qt];
-    if (g == 0 && qi < L) p.lse[((long)n * p.H + h) * L + qi] = m[qt] + __logf(l[qt]);
-    f4 t[4];
+    for (int t = 0; t < 2; ++t)
+      raw[t] = *reinterpret_cast<const u4v*>(q + (long)min(qt * 16 + (lane >> 3) + 8 * t, L - 1) * ld + 8 * (lane & 7));
+  };
+  u4v qraw[2], qnext[2];
+  load_q(min(wid, nqt - 1), qraw);
+  for (int qt = wid; qt < nqt; qt += 4) {
+    const int q0 = qt * 16, qi = q0 + c;
+    load_q(min(qt + 4, nqt - 1), qnext);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) t[dt] = acc[dt][qt] * inv;
-    store_row16(o, D, t, qi, qi < L, lane);
+    for (int t = 0; t < 2; ++t)
+      *reinterpret_cast<u4v*>(scr + ((lane >> 3) + 8 * t) * LDS_STRIDE + 8 * (lane & 7)) = qraw[t];
+    h8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const h8*>(scr + c * LDS_STRIDE + ks * 32 + 8 * g);
+    // S^T[key][q]: lane holds keys kt*16 + 4g + r of query column qi, for every key tile
+    f4 s[KTL];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {         // the K fragments of half the key tiles are requested together, then multiplied
+      h8 kf[KTL / 2][2];
+#pragma unroll
+      for (int i = 0; i < KTL / 2; ++i) {
+        const half_t* kr = ktile + ((half * (KTL / 2) + i) * 16 + c) * LDS_STRIDE + 8 * g;
+        kf[i][0] = *reinterpret_cast<const h8*>(kr);
+        kf[i][1] = *reinterpret_cast<const h8*>(kr + 32);
+      }
+#pragma unroll
+      for (int i = 0; i < KTL / 2; ++i) {
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][0], qf[0], z, 0, 0, 0);
+        s[half * (KTL / 2) + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][1], qf[1], z, 0, 0, 0);
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KTL; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        float val = s[kt][r] * (0.125f * LOG2E);                  // base-2 exponent: exp(x) = exp2(x log2 e)
+        // keys past L can only sit in the last two tiles (KTL = key tiles rounded up to an even count): no test elsewhere
+        if (CAUSAL) val = (key < L && (key <= qi || qi >= L)) ? val : -INFINITY;
+        else if (kt >= KTL - 2) val = key < L ? val : -INFINITY;
+        s[kt][r] = val;
+        m = fmaxf(m, val);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KTL; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);
+        s[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (g == 0 && qi < L) p.lse[((long)n * p.H + h) * L + qi] = (m + __log2f(sum)) * (1.0f / LOG2E);
+    h4 pt[KTL];
+#pragma unroll
+    for (int kt = 0; kt < KTL; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pt[kt][r] = (half_t)(s[kt][r] * inv);
+    // O^T[d][q] = sum_key V[key][d] P[q][key]; k-step ks covers key tiles 2ks, 2ks+1 in permuted order
+    f4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KTL / 2; ++ks)
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(vtile, ks * 32, ks * 32 + 16, dt * 16, lane),
+                                                         cat4(pt[2 * ks], pt[2 * ks + 1]), acc[dt], 0, 0, 0);
+    }
+    store_rows(o, D, acc, q0, L, scr, lane);
+    qraw[0] = qnext[0]; qraw[1] = qnext[1];
   }
 }
 
@@ -371,11 +386,32 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_kernel(AttnArgs p) {
 
 }  // namespace
 
+template <int KTL, bool CAUSAL>
+static void launch_long_fwd2(const AttnArgs& p, hipStream_t stream) {
+  constexpr int LDS = (2 * 16 * KTL + 4 * 16) * LDS_STRIDE * 2;            // K, V tiles + one 16-row staging tile per wave
+  if (LDS > 64 * 1024) {
+    static bool done[HMMC_MAX_DEVICES] = {false};
+    hmmc_allow_lds((const void*)attn_long_fwd_kernel<KTL, CAUSAL>, LDS, done);
+  }
+  hipLaunchKernelGGL((attn_long_fwd_kernel<KTL, CAUSAL>), dim3((unsigned)(p.nseq * p.H)), dim3(256), LDS, stream, p);
+}
+template <int KTL>
+static void launch_long_fwd(const AttnArgs& p, hipStream_t stream) {
+  if (p.causal) launch_long_fwd2<KTL, true>(p, stream); else launch_long_fwd2<KTL, false>(p, stream);
+}
+
 int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream) {
-  const int nqb = (p.L + 63) / 64;
-  long waves = (long)p.nseq * p.H * nqb;
-  const int lds = 4 * 64 * LDS_STRIDE * 2;
-  hipLaunchKernelGGL(attn_long_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, stream, p);
+  if ((long)p.nseq * p.H >= (1l << 31)) return HMMC_ERR_UNSUPPORTED;
+  const int ktl = ((p.L + 31) / 32) * 2;                                    // key tiles, rounded up to an even count
+  switch (ktl) {
+    case 6: launch_long_fwd<6>(p, stream); break;
+    case 8: launch_long_fwd<8>(p, stream); break;
+    case 10: launch_long_fwd<10>(p, stream); break;
+    case 12: launch_long_fwd<12>(p, stream); break;
+    case 14: launch_long_fwd<14>(p, stream); break;
+    case 16: launch_long_fwd<16>(p, stream); break;
+    default: return HMMC_ERR_UNSUPPORTED;
+  }
   return hmmc_launch_status();
 }
 

@@ -41,4 +41,27 @@ __device__ __forceinline__ h8 tr_frag(const half_t* tile, int rA, int rB, int c0
 }
 
 
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+// X^T[d = dt*16 + 4g + r][row = c] accumulators (4 d-tiles) of the 16 rows row0 .. row0 + 15 -> global [row][64].  The
+// strip goes through a 16 x 144 B LDS scratch (8-byte writes from the MFMA layout, 16-byte reads in lane order) so that
+// every store instruction writes 8 full 128-byte rows with consecutive lanes on consecutive bytes; a wave's LDS
+// operations execute in order, so strips follow each other without a wait.
+__device__ __forceinline__ void store_rows(half_t* dst, long ld, const f4 (&acc)[4], int row0, int L, half_t* scr, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    h4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (half_t)acc[dt][r];
+    *reinterpret_cast<h4*>(scr + c * LDS_STRIDE + dt * 16 + 4 * g) = v;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int r = (lane >> 3) + 8 * t;
+    const u4v o = *reinterpret_cast<const u4v*>(scr + r * LDS_STRIDE + 8 * (lane & 7));
+    if (row0 + r < L) *reinterpret_cast<u4v*>(dst + (long)(row0 + r) * ld + 8 * (lane & 7)) = o;
+  }
+}
+
 }  // namespace

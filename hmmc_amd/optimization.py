@@ -50,8 +50,15 @@ class _TensorTable:
     def build(self, rows):
         """rows: list of (ptr0, ptr1, ptr2, ptr3, numel, dtype_flag[, group]).  The tables are staged through pinned
         memory and copied asynchronously: building them never blocks the host behind queued GPU work."""
-        key = tuple(rows)
-        if key != self.key:
+        if isinstance(rows, np.ndarray):                 # the per-step fast paths hand over an int64 [n, k] array
+            if self.key is not None and isinstance(self.key, np.ndarray) and np.array_equal(rows, self.key):
+                return self
+            key = rows.copy()
+        else:
+            key = tuple(rows)
+            if isinstance(self.key, tuple) and key == self.key:
+                return self
+        if True:
             arr = np.zeros((len(rows), 8), dtype=np.int64)
             arr[:, :len(rows[0])] = np.asarray(rows, dtype=np.int64)
             nch = (arr[:, 4] + self.chunk_elems - 1) // self.chunk_elems
@@ -81,15 +88,26 @@ _clip_tables = {}
 def clip_grad_norm_(parameters, max_norm):
     """torch.nn.utils.clip_grad_norm_(parameters, max_norm) semantics (main_task_retrieval.py:291) in three
     launches over all gradients.  Returns the total norm (0-dim device tensor, no host sync)."""
-    params = [p for p in parameters if p.grad is not None]
-    if not params:
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
         return torch.zeros(())
-    dev = params[0].grad.device
+    dev = grads[0].device
     tbl = _clip_tables.setdefault(str(dev), _TensorTable(dev))
-    rows = [(0, p.grad.data_ptr(), 0, 0, p.grad.numel(), _dtype_flag(p.grad)) for p in params]
-    for p in params:
-        if not p.grad.is_contiguous():
-            raise ValueError("gradients must be contiguous")
+    # per step only the gradient pointers can change (and in steady state the caching allocator hands the same ones back):
+    # the static columns are kept with the table and the device copy is refreshed only when a pointer moved
+    ptrs = np.fromiter((g.data_ptr() for g in grads), dtype=np.int64, count=len(grads))
+    sig = (len(grads), sum(g.numel() for g in grads))
+    if getattr(tbl, "_sig", None) != sig:
+        for g in grads:
+            if not g.is_contiguous():
+                raise ValueError("gradients must be contiguous")
+        static = np.zeros((len(grads), 6), dtype=np.int64)
+        static[:, 4] = [g.numel() for g in grads]
+        static[:, 5] = [_dtype_flag(g) for g in grads]
+        tbl._static, tbl._sig = static, sig
+    static = tbl._static
+    rows = static.copy()
+    rows[:, 1] = ptrs
     tbl.build(rows)
     out = torch.empty(2, dtype=torch.float32, device=dev)
     call("hmmc_mt_clip_grad_norm", ptr(tbl.tab), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T, float(max_norm), ptr(out))
@@ -117,6 +135,64 @@ class BertAdam(Optimizer):
                         weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         super().__init__(params, defaults)
         self._table = None
+        self._fast = None
+
+    # ---- steady-state fast path.  step() above walks 350-560 parameters in Python every call (state lookups, schedule, tuple
+    # rows: 2 ms of host time, which at small per-GPU batches is what the step waits for).  Once a full step has shown that
+    # every parameter has a gradient and the parameters of a group share their step count, the static part of the table (weights,
+    # moments, sizes, group index) is kept and a step only reads the gradient pointers and evaluates the schedule per group.
+    def _plan_fast_path(self, n_rows, n_hp_rows):
+        self._fast = None
+        groups = [g for g in self.param_groups if g["params"]]
+        params = [p for g in groups for p in g["params"]]
+        if n_rows != len(params) or n_hp_rows != len(groups) or len(groups) > 32:
+            return                                   # some gradient was None, or a group's parameters differ in step count
+        static = np.zeros((len(params), 7), dtype=np.int64)
+        row = 0
+        for gi, g in enumerate(groups):
+            for p in g["params"]:
+                st = self.state[p]
+                static[row] = (p.data_ptr(), 0, st["next_m"].data_ptr(), st["next_v"].data_ptr(), p.numel(), _dtype_flag(p), gi)
+                row += 1
+        self._fast = {"groups": groups, "params": params, "static": static, "states": [self.state[p] for p in params],
+                      "table": _TensorTable(params[0].device)}
+
+    def _fast_step(self):
+        fp = getattr(self, "_fast", None)
+        if fp is None:
+            return False
+        grads = [p.grad for p in fp["params"]]
+        ps, static = fp["params"], fp["static"]
+        if (any(g is None for g in grads) or sum(len(g["params"]) for g in self.param_groups) != len(grads)
+                or any(ps[i].data_ptr() != static[i, 0] or self.state[ps[i]]["next_m"].data_ptr() != static[i, 2]
+                       for i in (0, len(ps) // 2, len(ps) - 1))):      # parameters moved / optimizer state reloaded
+            self._fast = None
+            return False
+        hp = []
+        for g in fp["groups"]:
+            steps = {self.state[p]["step"] for p in (g["params"][0], g["params"][-1])}
+            if len(steps) != 1:
+                self._fast = None
+                return False
+            step = steps.pop()
+            lr_s = g["lr"] * SCHEDULES[g["schedule"]](step / g["t_total"], g["warmup"]) if g["t_total"] != -1 else g["lr"]
+            hp += [lr_s, g["weight_decay"], g["b1"], g["b2"], g["e"], g["max_grad_norm"], 1 - g["b1"], 1 - g["b2"]]
+        rows = fp["static"].copy()
+        rows[:, 1] = np.fromiter((g.data_ptr() for g in grads), dtype=np.int64, count=len(grads))
+        tbl = fp["table"].build(rows)
+        hp_host = (ctypes.c_float * len(hp))(*hp)
+        call("hmmc_mt_bertadam", ptr(tbl.tab), hp_host, len(fp["groups"]), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T)
+        for st in fp["states"]:
+            st["step"] += 1
+        return True
+
+    def load_state_dict(self, state_dict):
+        self._fast, self._table = None, None                  # the cached tables point at the old moment tensors
+        return super().load_state_dict(state_dict)
+
+    def add_param_group(self, param_group):
+        self._fast, self._table = None, None
+        return super().add_param_group(param_group)
 
     def get_lr(self):
         lr = []
@@ -140,6 +216,8 @@ class BertAdam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self._fast_step():
+            return loss
         rows, frows = [], {}
         dev = None
         for gi, group in enumerate(self.param_groups):
@@ -172,6 +250,7 @@ class BertAdam(Optimizer):
             return loss
         if dev.type != "cuda":
             raise RuntimeError("hmmc_amd.BertAdam runs on the GPU only (no CPU fallback)")
+        self._plan_fast_path(len(rows), len(frows))
         if self._table is None:
             self._table = {}
         hps = list(frows)                                   # insertion order = row index
