@@ -26,6 +26,9 @@ SIGNATURES = {
     "hmmc_layernorm_fwd": ("pppppppiilfip", "i"),
     "hmmc_layernorm_bwd_workspace": ("ii", "z"),
     "hmmc_layernorm_bwd": ("pppppppppppiilipzp", "i"),
+    "hmmc_layernorm_bwd_rows": ("i", "i"),
+    "hmmc_layernorm_bwd_partial": ("ppppppppipiilip", "i"),
+    "hmmc_multi_colreduce": ("pip", "i"),
     "hmmc_colsum_workspace": ("ii", "z"),
     "hmmc_colsum": ("ppiiliiipzp", "i"),
     "hmmc_patchify_u8": ("pppiiiippp", "i"),
@@ -73,7 +76,7 @@ SIGNATURES = {
     "hmmc_ce_bwd": ("pppppilp", "i"),
     "hmmc_tower_act_bytes": ("liiiii", "z"),
     "hmmc_tower_bwd_scratch_bytes": ("lii", "z"),
-    "hmmc_tower_workspace_bytes": ("liii", "z"),
+    "hmmc_tower_workspace_bytes": ("liiii", "z"),
     "hmmc_tower_fwd": ("ppppiiiiiiifiipzp", "i"),
     "hmmc_tower_bwd": ("pppppppiiiiiiiipzpp", "i"),
 }

@@ -42,6 +42,7 @@ struct GemmArgs {
   float* csum;                  // EPI_COLSUM: fp32 [row blocks of 128 (256x256 tile) or 64 rows][N] partial column sums of C
   int M, N, K, lda, ldb, ldc;
   int flags, splitk, ktps;
+  int slab;                     // 1: write the fp32 partial slab even when splitk == 1 (pieces along K, reduced by the host's launch)
   unsigned a_bytes, b_bytes;
 };
 
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
 #if HMMC_DBG == 2
     _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(acc[i][j]));
 #else
-    if (p.splitk > 1)
+    if (p.splitk > 1 || p.slab)
       epilogue_slab<MT, NT>(p, acc, tm * BM + wm * (MT * 16) + (lane & 15), tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
     else
       epilogue_f16<MT, EPI>(p, acc, tm * BM + wm * (MT * 16), tn * BN + wn * (NT * 16), lane, smem + 2 * STAGE_BYTES + wid * EPI_LDS_PER_WAVE);
@@ -770,14 +771,40 @@ extern "C" size_t hmmc_gemm_f16_colsum_rows(int M, int N, int K) {
   return (size_t)((M + c.bm - 1) / c.bm) * 2;   // two wave rows per tile in both configurations
 }
 
+// ---- operands of 2 GiB and more -----------------------------------------------------------------------------------------
+// The kernels address their operands through 32-bit buffer offsets (with bit 31 as the "read zeros" escape of the staging
+// code), so one launch sees at most 2 GiB of A and of B.  Larger operands - the MLP activations of ViT-B/16 at B = 128,
+// F = 24 on ONE GPU are 605 184 tokens x 3072 x 2 B = 3.7 GB - are cut on the host, with 64-bit base pointers per piece:
+//   a k-major A (tokens x features: forward, data gradient) along M, every piece an independent GEMM on its rows;
+//   m-major operands (weight gradient: tokens are the K dimension) along K, every piece adding its split-K slabs to ONE
+//   fp32 slab set that a single reduce turns into the result (the weight-gradient path always has epilogue 0).
+// k_chunk_rows(ld): K rows one piece may span; m_chunk_rows(lda): rows of a k-major A.
+constexpr uint64_t PIECE_BYTES = (1ull << 31) - (1ull << 24);       // room for the 256-row / 64-k overreach of the last tile
+static inline long k_chunk_rows(int ld) { long r = (long)(PIECE_BYTES / ((uint64_t)ld * 2)); return r - r % BKT; }
+static inline long m_chunk_rows(int lda) { long r = (long)(PIECE_BYTES / ((uint64_t)lda * 2)); return r - r % 256; }
+static inline bool needs_k_pieces(int K, int lda, int ldb, bool a_kmajor, bool b_kmajor) {
+  return (!a_kmajor && (uint64_t)(K + BKT) * lda * 2 >= PIECE_BYTES) || (!b_kmajor && (uint64_t)(K + BKT) * ldb * 2 >= PIECE_BYTES);
+}
+
 extern "C" size_t hmmc_gemm_f16_workspace(int M, int N, int K) {
   TileCfg c = pick_cfg(M, N, K, true);
+  // a weight gradient over more tokens than one piece holds (assuming operands as wide as M and N) needs a slab per piece
+  const int ld = M > N ? M : N;
+  if (needs_k_pieces(K, ld, ld, false, false)) {
+    const long kc = k_chunk_rows(ld);
+    size_t slabs = 0;
+    for (long k0 = 0; k0 < K; k0 += kc) slabs += (size_t)pick_cfg(M, N, (int)((K - k0 < kc) ? K - k0 : kc), true).splitk;
+    return slabs * M * N * sizeof(float);
+  }
   return c.splitk > 1 ? (size_t)c.splitk * M * N * sizeof(float) : 0;
 }
 
-extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                             int a_kmajor, int b_kmajor, const void* bias, const void* resid, void* aux_out,
-                             const void* aux_in, int epilogue, void* workspace, size_t ws_bytes, hipStream_t stream) {
+// one launch (+ its split-K reduce).  slab_mode 0: ordinary call.  slab_mode 1 (pieces along K): the fp32 partial slabs go to
+// `workspace` (at least one, even without a split), no reduce; *slabs_out = slabs written.
+static int gemm_f16_one(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                        int a_kmajor, int b_kmajor, const void* bias, const void* resid, void* aux_out,
+                        const void* aux_in, int epilogue, void* workspace, size_t ws_bytes, hipStream_t stream,
+                        int slab_mode, int* slabs_out) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return HMMC_ERR_ARG;
   if ((lda & 7) || (ldb & 7) || (ldc & 7) || (N & 7)) return HMMC_ERR_UNSUPPORTED;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)resid | (uintptr_t)aux_in | (uintptr_t)aux_out) & 15) return HMMC_ERR_UNSUPPORTED;
@@ -811,6 +838,11 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
   if (splitk > 1 && (!workspace || ws_bytes < (size_t)splitk * M * N * sizeof(float))) splitk = 1;
   p.ktps = (nkt + splitk - 1) / splitk;
   splitk = (nkt + p.ktps - 1) / p.ktps;        // every split owns at least one K-tile
+  if (slab_mode) {
+    if (!workspace || ws_bytes < (size_t)splitk * M * N * sizeof(float)) return HMMC_ERR_WORKSPACE;
+    *slabs_out = splitk;
+  }
+  p.slab = slab_mode;
   p.splitk = splitk;
   p.ws = (float*)workspace;
   long tiles = (long)((M + cfg.bm - 1) / cfg.bm) * ((N + cfg.bn - 1) / cfg.bn);
@@ -830,12 +862,65 @@ extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N
   }
   if (cfg.bm == 256) launch_cfg<256, 256, 2, 4>(p, a_kmajor, b_kmajor, grid, stream);
   else launch_cfg<128, 128, 2, 2>(p, a_kmajor, b_kmajor, grid, stream);
-  if (splitk > 1) {
+  if (splitk > 1 && !slab_mode) {
     size_t nb = ((size_t)M * N / 4 + 255) / 256;
     int blocks = (int)(nb < 2048 ? nb : 2048);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, (half_t*)C, M, N,
                        ldc, splitk);
   }
   if (rec.e0) { (void)hipEventRecord(rec.e1, stream); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(rec); }
+  return hmmc_launch_status();
+}
+
+extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                             int a_kmajor, int b_kmajor, const void* bias, const void* resid, void* aux_out,
+                             const void* aux_in, int epilogue, void* workspace, size_t ws_bytes, hipStream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return HMMC_ERR_ARG;
+  const bool big_m = a_kmajor && (uint64_t)(M + 256) * lda * 2 >= PIECE_BYTES;
+  const bool big_k = needs_k_pieces(K, lda, ldb, a_kmajor != 0, b_kmajor != 0);
+  if (!big_m && !big_k)
+    return gemm_f16_one(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, resid, aux_out, aux_in, epilogue, workspace,
+                        ws_bytes, stream, 0, nullptr);
+  const char* a8 = (const char*)A;
+  const char* b8 = (const char*)B;
+  if (big_m && !big_k) {                         // pieces of whole 256-row tiles; the column-sum partials follow the rows
+    const long mc = m_chunk_rows(lda);
+    if (mc < 256) return HMMC_ERR_UNSUPPORTED;
+    size_t cs_off = 0;
+    for (long m0 = 0; m0 < M; m0 += mc) {
+      const int mp = (int)((M - m0 < mc) ? M - m0 : mc);
+      const size_t roff = (size_t)m0 * ldc * 2;
+      void* ws = workspace;
+      size_t wsb = ws_bytes;
+      if (epilogue & EPI_COLSUM) {
+        if (pick_cfg(mp, N, K, false).bm != pick_cfg(M, N, K, false).bm) return HMMC_ERR_UNSUPPORTED;
+        ws = (char*)workspace + cs_off;
+        wsb = ws_bytes > cs_off ? ws_bytes - cs_off : 0;
+        cs_off += hmmc_gemm_f16_colsum_rows(mp, N, K) * N * sizeof(float);
+      }
+      int rc = gemm_f16_one(a8 + (size_t)m0 * lda * 2, B, (char*)C + roff, mp, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias,
+                            resid ? (const char*)resid + roff : nullptr, aux_out ? (char*)aux_out + roff : nullptr,
+                            aux_in ? (const char*)aux_in + roff : nullptr, epilogue, ws, wsb, stream, 0, nullptr);
+      if (rc) return rc;
+    }
+    return HMMC_OK;
+  }
+  if (big_m || epilogue != 0 || a_kmajor || b_kmajor) return HMMC_ERR_UNSUPPORTED;     // K pieces: the weight-gradient layout only
+  long kc = k_chunk_rows(lda > ldb ? lda : ldb);
+  if (kc < BKT) return HMMC_ERR_UNSUPPORTED;
+  int slabs = 0;
+  for (long k0 = 0; k0 < K; k0 += kc) {
+    const int kp = (int)((K - k0 < kc) ? K - k0 : kc);
+    const size_t used = (size_t)slabs * M * N * sizeof(float);
+    if (!workspace || ws_bytes <= used) return HMMC_ERR_WORKSPACE;
+    int wrote = 0;
+    int rc = gemm_f16_one(a8 + (size_t)k0 * lda * 2, b8 + (size_t)k0 * ldb * 2, C, M, N, kp, lda, ldb, ldc, 0, 0, nullptr, nullptr,
+                          nullptr, nullptr, 0, (char*)workspace + used, ws_bytes - used, stream, 1, &wrote);
+    if (rc) return rc;
+    slabs += wrote;
+  }
+  size_t nb = ((size_t)M * N / 4 + 255) / 256;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, stream, (const float*)workspace,
+                     (half_t*)C, M, N, ldc, slabs);
   return hmmc_launch_status();
 }

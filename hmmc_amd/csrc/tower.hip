@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 extern "C" {
 int hmmc_gemm_f16(const void*, const void*, void*, int, int, int, int, int, int, int, int, const void*, const void*, void*,
@@ -24,6 +25,10 @@ int hmmc_layernorm_fwd(const void*, const float*, const float*, void*, float*, f
 int hmmc_layernorm_bwd(const void*, const void*, const float*, const float*, const float*, const void*, void*, float*, float*,
                        void*, const int*, int, int, long, int, void*, size_t, hipStream_t);
 size_t hmmc_layernorm_bwd_workspace(int, int);
+int hmmc_layernorm_bwd_rows(int);
+int hmmc_layernorm_bwd_partial(const void*, const void*, const float*, const float*, const float*, const void*, void*, float*, int,
+                               const int*, int, int, long, int, hipStream_t);
+int hmmc_multi_colreduce(const void*, int, hipStream_t);
 int hmmc_colsum(const void*, void*, int, int, long, int, int, int, void*, size_t, hipStream_t);
 size_t hmmc_colsum_workspace(int, int);
 int hmmc_attention_f16_fwd(const void*, void*, float*, int, int, int, int, hipStream_t);
@@ -110,13 +115,21 @@ extern "C" size_t hmmc_tower_bwd_scratch_bytes(long tokens, int D, int fp32) {
   return al((size_t)tokens * 4 * D * es) + al((size_t)tokens * 3 * D * es) + 4 * al((size_t)tokens * D * es);
 }
 
-// fp32 partial sums of the fused bias gradients (fp16 tower): c_fc bias from the QuickGELU' dgrad epilogue
-// [colsum_rows][4D], in_proj bias from the attention backward [nseq][3D]; one region, used one after the other
-static size_t partial_bytes(long tokens, int D, int nseq) {
-  size_t a = hmmc_gemm_f16_colsum_rows((int)tokens, 4 * D, D) * (size_t)4 * D * sizeof(float);
-  size_t b = (size_t)nseq * 3 * D * sizeof(float);
-  return al(a > b ? a : b);
+// fp32 partial sums of the fp16 tower's deferred reductions, one slot per layer (hmmc_tower_bwd reduces all of them in one
+// launch at its end): LayerNorm 2 and LayerNorm 1 ([ln rows][3D]: dgamma | dbeta | column sums of dx), the c_fc bias from the
+// QuickGELU' dgrad epilogue [colsum_rows][4D], the in_proj bias from the attention backward [nseq][3D]
+struct ReduceTask { const float* partial; int R, N, seg; void* out[3]; int dtype[3]; };     // = HmmcReduceTask
+struct PartSlot { size_t ln2, ln1, fc, attn, bytes; };
+static PartSlot part_slot(long tokens, int D, int nseq) {
+  PartSlot p;
+  const size_t ln = al((size_t)hmmc_layernorm_bwd_rows((int)tokens) * 3 * D * sizeof(float));
+  p.ln2 = 0; p.ln1 = ln;
+  p.fc = 2 * ln;
+  p.attn = p.fc + al(hmmc_gemm_f16_colsum_rows((int)tokens, 4 * D, D) * (size_t)4 * D * sizeof(float));
+  p.bytes = p.attn + al((size_t)nseq * 3 * D * sizeof(float));
+  return p;
 }
+static size_t partial_bytes(long tokens, int D, int nseq, int layers) { return part_slot(tokens, D, nseq).bytes * (size_t)(layers > 0 ? layers : 0); }
 
 static size_t general_bytes(long tokens, int D, int fp32) {
   size_t w = hmmc_layernorm_bwd_workspace((int)tokens, D);
@@ -147,10 +160,10 @@ static size_t wgrad_ws_bytes(long tokens, int D, int fp32) {
   return al(g);
 }
 
-// [general: LayerNorm / column-sum / split-K slabs][fp16 tower: bias-gradient partials][split-K slabs of the
-// weight-gradient stream]
-extern "C" size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32) {
-  return general_bytes(tokens, D, fp32) + (fp32 ? 0 : partial_bytes(tokens, D, nseq)) + wgrad_ws_bytes(tokens, D, fp32);
+// [general: LayerNorm / column-sum / split-K slabs][fp16 tower backward: per-layer slots of deferred-reduction partials]
+// [split-K slabs of the weight-gradient stream]
+extern "C" size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32, int bwd_layers) {
+  return general_bytes(tokens, D, fp32) + (fp32 ? 0 : partial_bytes(tokens, D, nseq, bwd_layers)) + wgrad_ws_bytes(tokens, D, fp32);
 }
 
 // y = tower(x).  keep_acts: acts holds nlayers slabs (training); otherwise one slab is reused (key encoders, eval).
@@ -256,11 +269,26 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
   // produce the tensors (LayerNorm backward: out_proj / c_proj; QuickGELU' dgrad epilogue: c_fc; attention backward:
   // in_proj) instead of re-reading them.  Only the c_proj bias of the LAST layer still needs its own pass over dy.
   const size_t gen = general_bytes(T, D, fp32);
-  const size_t part_bytes = f32 ? 0 : partial_bytes(T, D, nseq);
+  const size_t part_bytes = f32 ? 0 : partial_bytes(T, D, nseq, nlayers);
   const size_t wws_bytes = wgrad_ws_bytes(T, D, fp32);
   if (ws_bytes < gen + part_bytes + wws_bytes) return HMMC_ERR_WORKSPACE;
-  float* part = f32 ? nullptr : (float*)((char*)workspace + gen);
+  const PartSlot slot = f32 ? PartSlot{} : part_slot(T, D, nseq);
+  char* const part_base = (char*)workspace + gen;
   void* wws = (char*)workspace + gen + part_bytes;
+  // second-stage reductions of the fp16 tower, all in one launch at the end (none of their results is read before)
+  std::vector<ReduceTask> tasks;
+  auto defer = [&](const float* partial, int R, int N, int seg, void* o0, int d0, void* o1 = nullptr, int d1 = 1, void* o2 = nullptr,
+                   int d2 = 1) { tasks.push_back(ReduceTask{partial, R, N, seg, {o0, o1, o2}, {d0, d1, d2}}); };
+  // LayerNorm backward: fp32 towers reduce at once, fp16 towers leave the partial matrix in the layer's slot
+  auto ln_bwd = [&](const void* dyp, const void* xp, const float* gm, const float* mean, const float* rstd, const void* dres,
+                    void* dxp, float* dgamma, float* dbeta, void* dx_colsum, int rows, long stride, float* slotp) -> int {
+    if (f32)
+      return hmmc_layernorm_bwd(dyp, xp, gm, mean, rstd, dres, dxp, dgamma, dbeta, dx_colsum, nullptr, rows, D, stride, dt, workspace,
+                                gen, s);
+    int rc = hmmc_layernorm_bwd_partial(dyp, xp, gm, mean, rstd, dres, dxp, slotp, dx_colsum != nullptr, nullptr, rows, D, stride, dt, s);
+    if (rc == 0) defer(slotp, hmmc_layernorm_bwd_rows(rows), (dx_colsum ? 3 : 2) * D, D, dgamma, 1, dbeta, 1, dx_colsum, dt);
+    return rc;
+  };
   hipStream_t sw = wgrad_stream ? wgrad_stream : s;
   const bool two = sw != s;
   WgradSync* const syncp = two ? wgrad_sync_for(s, sw) : nullptr;
@@ -294,6 +322,12 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
     Acts a = carve((char*)acts + (size_t)i * slab, T, D, nseq, L, heads, es, f32);
     const void* xin = i == 0 ? x0 : (const void*)a.x;
     void* g_out = i == 0 ? dx : ping[i & 1];
+    char* const sl = part_base + (size_t)i * slot.bytes;           // this layer's slot of partial matrices (fp16 tower)
+    float* const p_ln2 = (float*)(sl + slot.ln2);
+    float* const p_ln1 = (float*)(sl + slot.ln1);
+    float* const p_fc = (float*)(sl + slot.fc);
+    float* const p_attn = (float*)(sl + slot.attn);
+    const size_t fc_bytes = slot.attn - slot.fc, attn_bytes = slot.bytes - slot.attn;
     if (lead_only && i + 1 == nlayers) {
       // Last block, leading rows only (see hmmc_tower_fwd): g_in = dy and x1 / att are addressed at stride L*D, dh / dln / ln2 /
       // g / h are compact [nseq, .].  dx1 and the attention-output gradient are full [T, D] buffers that the attention and
@@ -302,12 +336,12 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
       CK(side_wgrad(0, g_in, a.g, G[10], D, 4 * D, nseq, ldl, 0));
       const int rows = (int)hmmc_gemm_f16_colsum_rows(nseq, 4 * D, D);
       CK(hmmc_gemm_f16(g_in, P[10], dh, nseq, 4 * D, D, ldl, 4 * D, 4 * D, 1, 0, nullptr, nullptr, nullptr, a.h,
-                       EPI_MULAUX | EPI_COLSUM, part, part_bytes, s));
-      CK(hmmc_colsum(part, G[9], rows, 4 * D, 4 * D, 1, dt, 0, workspace, gen, s));
+                       EPI_MULAUX | EPI_COLSUM, p_fc, fc_bytes, s));
+      defer(p_fc, rows, 4 * D, 4 * D, G[9], dt);
       CK(side_wgrad(1, dh, a.ln2, G[8], 4 * D, D, nseq));
       CK(dgrad(f32, dh, P[8], dln, nseq, 4 * D, D, nullptr, 0, s));
-      CK(hmmc_layernorm_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], G[5], nullptr,
-                            nseq, D, ldl, dt, workspace, gen, s));             // G[5]: out_proj bias = colsum(dx1 rows)
+      CK(ln_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], G[5], nseq, ldl,
+                p_ln2));                                                       // G[5]: out_proj bias = colsum(dx1 rows)
       CK(side_wgrad(2, dx1, a.att, G[4], D, D, nseq, ldl, ldl));
       if (hipMemsetAsync(dln, 0, (size_t)T * D * es, s) != hipSuccess) return HMMC_ERR_LAUNCH;
       CK(hmmc_gemm_f16(dx1, P[4], dln, nseq, D, D, ldl, D, ldl, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, s));
@@ -320,14 +354,14 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
       CK(hmmc_colsum(dh, G[9], (int)T, 4 * D, 4 * D, dt, dt, 0, workspace, gen, s));
     } else {
       const int rows = (int)hmmc_gemm_f16_colsum_rows((int)T, 4 * D, D);
-      CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_MULAUX, s, part, part_bytes));
-      CK(hmmc_colsum(part, G[9], rows, 4 * D, 4 * D, 1, dt, 0, workspace, gen, s));
+      CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_MULAUX, s, p_fc, fc_bytes));
+      defer(p_fc, rows, 4 * D, 4 * D, G[9], dt);
     }
     CK(side_wgrad(1, dh, a.ln2, G[8], 4 * D, D));
     CK(dgrad(f32, dh, P[8], dln, (int)T, 4 * D, D, nullptr, 0, s));
     CK(before_overwrite(2));
-    CK(hmmc_layernorm_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], G[5], nullptr,
-                          (int)T, D, D, dt, workspace, gen, s));               // G[5]: out_proj bias = colsum(dx1)
+    CK(ln_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], G[5], (int)T, D,
+              p_ln2));                                                         // G[5]: out_proj bias = colsum(dx1)
     // attention: x1 = x + out_proj(attn(in_proj(ln1)))
     CK(side_wgrad(2, dx1, a.att, G[4], D, D));
     CK(dgrad(f32, dx1, P[4], dln, (int)T, D, D, nullptr, 0, s));                 // datt (reuses dln)
@@ -337,8 +371,9 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
       CK(hmmc_temporal_attention_bwd((const float*)a.qkv, a.stat, (const float*)dln, (float*)dqkv, nseq, L, heads, s));
       CK(hmmc_colsum(dqkv, G[3], (int)T, 3 * D, 3 * D, dt, dt, 0, workspace, gen, s));
     } else if (L <= 64) {
-      CK(hmmc_attention_f16_bwd(a.qkv, a.att, a.stat, dln, dqkv, part, nseq, L, heads, causal, s));
-      CK(hmmc_colsum(part, G[3], nseq, 3 * D, 3 * D, 1, dt, 0, workspace, gen, s));
+      CK(hmmc_attention_f16_bwd(a.qkv, a.att, a.stat, dln, dqkv, p_attn, nseq, L, heads, causal, s));
+      defer(p_attn, nseq, 3 * D, 3 * D, G[3], dt);
+      (void)attn_bytes;
     } else {
       CK(hmmc_attention_f16_bwd(a.qkv, a.att, a.stat, dln, dqkv, nullptr, nseq, L, heads, causal, s));
       CK(hmmc_colsum(dqkv, G[3], (int)T, 3 * D, 3 * D, dt, dt, 0, workspace, gen, s));
@@ -348,10 +383,11 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
     // the c_proj bias gradient of the layer below is the column sum of the dx this call writes (into the buffer weight
     // gradient 0 of the layer above read as its g_in)
     CK(before_overwrite(0));
-    CK(hmmc_layernorm_bwd(dln, xin, (const float*)P[0], a.m1, a.r1, dx1, g_out, (float*)G[0], (float*)G[1],
-                          i > 0 ? grads[(size_t)(i - 1) * 12 + 11] : nullptr, nullptr, (int)T, D, D, dt, workspace, gen, s));
+    CK(ln_bwd(dln, xin, (const float*)P[0], a.m1, a.r1, dx1, g_out, (float*)G[0], (float*)G[1],
+              i > 0 ? grads[(size_t)(i - 1) * 12 + 11] : nullptr, (int)T, D, p_ln1));
     g_in = g_out;
   }
+  if (!tasks.empty()) CK(hmmc_multi_colreduce(tasks.data(), (int)tasks.size(), s));
   if (two) {                                     // hand the weight gradients back in `s` order
     if (hipEventRecord(syncp->ready, sw) != hipSuccess || hipStreamWaitEvent(s, syncp->ready, 0) != hipSuccess) return HMMC_ERR_LAUNCH;
   }

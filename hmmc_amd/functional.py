@@ -104,7 +104,7 @@ def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep, lead_only
     nl = len(params) // PER_LAYER
     slab = query("hmmc_tower_act_bytes", T, D, nseq, L, heads, int(fp32))
     acts = torch.empty(slab * (nl if keep else 1), dtype=torch.uint8, device=x.device)
-    wsb = query("hmmc_tower_workspace_bytes", T, D, nseq, int(fp32))
+    wsb = query("hmmc_tower_workspace_bytes", T, D, nseq, int(fp32), 0)
     ws = ops.workspace(wsb, x.device, "tower")
     y = torch.empty_like(x)
     call("hmmc_tower_fwd", ptr(x), ptr(y), _ptr_array(params), ptr(acts), int(keep), nseq, L, heads, D, nl, int(causal),
@@ -121,7 +121,7 @@ def _tower_backward(dy, x0, params, acts, nseq, L, heads, causal, fp32, lead_onl
     nl = len(params) // PER_LAYER
     grads = [torch.empty_like(p) for p in params]
     scratch = torch.empty(query("hmmc_tower_bwd_scratch_bytes", T, D, int(fp32)), dtype=torch.uint8, device=x0.device)
-    wsb = query("hmmc_tower_workspace_bytes", T, D, nseq, int(fp32))
+    wsb = query("hmmc_tower_workspace_bytes", T, D, nseq, int(fp32), nl)
     ws = ops.workspace(wsb, x0.device, "tower")
     dx = torch.empty_like(x0)
     # weight gradients on their own stream (leaves of the backward): the library orders the two streams itself

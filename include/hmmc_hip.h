@@ -84,6 +84,18 @@ int hmmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
                        const void* dres, void* dx, float* dgamma, float* dbeta, void* dx_colsum, const int* row_index,
                        int rows, int D, long in_stride, int dtype, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
 
+/* The two stages of hmmc_layernorm_bwd separately, for callers that batch the second one (hmmc_tower_bwd):
+ * hmmc_layernorm_bwd_partial writes dx and the fp32 partial matrix [hmmc_layernorm_bwd_rows(rows)][np * D], np = 2
+ * (dgamma | dbeta) or 3 (... | column sums of dx); hmmc_multi_colreduce sums the rows of up to many such matrices in ONE
+ * launch: task t writes out[c / seg][c % seg] = sum_r partial[r][c] with the given dtype (0 fp16, 1 fp32; out[] entries may
+ * be NULL, N <= 3 seg).  `tasks` is a HOST array. */
+typedef struct HmmcReduceTask { const float* partial; int R, N, seg; void* out[3]; int dtype[3]; } HmmcReduceTask;
+int hmmc_layernorm_bwd_rows(int rows);
+int hmmc_layernorm_bwd_partial(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                               const void* dres, void* dx, float* partial, int want_dx_colsum, const int* row_index, int rows,
+                               int D, long in_stride, int dtype, hmmc_stream_t stream);
+int hmmc_multi_colreduce(const void* tasks, int ntasks, hmmc_stream_t stream);
+
 /* out[n] = sum_m X[m][n] (bias, class/positional-embedding gradients). dtypes: 0 fp16, 1 fp32. */
 size_t hmmc_colsum_workspace(int M, int N);
 int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int in_dtype, int out_dtype, int round_f16,
@@ -246,7 +258,7 @@ int hmmc_ce_bwd(float* logits, const long* labels, const float* lse, const float
  * hmmc_tower_workspace_bytes().  Only sequences this library's kernels on `stream`. */
 size_t hmmc_tower_act_bytes(long tokens, int D, int nseq, int L, int heads, int fp32);
 size_t hmmc_tower_bwd_scratch_bytes(long tokens, int D, int fp32);
-size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32);
+size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32, int bwd_layers);   /* bwd_layers: 0 for hmmc_tower_fwd, nlayers for hmmc_tower_bwd */
 /* lead_only (fp16 towers, 0 / 1): the caller consumes only token 0 of every sequence of y - the ViT class token, the only
  * row VisualEncoder.encode_image keeps (modules/module_cross.py:228-230).  The last block's out_proj, ln_2 and MLP are
  * per-token, so they then run on the nseq leading rows alone (addressed in place at stride L*D); the other rows of y are

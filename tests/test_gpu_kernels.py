@@ -79,6 +79,37 @@ def test_gemm_big_tile_exact_integers(layout, M, N, K):
     assert torch.equal(c.float(), ref), f"max diff {(c.float()-ref).abs().max()}"
 
 
+@pytest.mark.parametrize("layout", ["kk", "km", "mm"])
+def test_gemm_operands_beyond_2gib(layout):
+    """An operand of 2 GiB or more (SURVEY config 5 on one GPU: 605 184 tokens x 3072 fp16 = 3.7 GB) exceeds what one launch's
+    32-bit buffer offsets reach: the entry point cuts it into pieces (rows of a k-major A, token ranges of the weight-gradient
+    operands whose split-K slabs meet in one reduce) and the result is still exact."""
+    T, W = 360448, 3072                                  # 2.2 GB per [T, W] fp16 operand
+    g = torch.Generator(device=DEV).manual_seed(7)
+    big = torch.randint(-1, 2, (T, W), device=DEV, dtype=torch.int8, generator=g).half()
+    if layout == "kk":                                   # forward: y[T, 256] = x[T, W] w[256, W]^T + bias, + residual
+        w, bias = ints(256, W, lo=-1, hi=2, seed=1), ints(256, lo=-2, hi=3, seed=2)
+        res = torch.randint(-2, 3, (T, 256), device=DEV, dtype=torch.int8, generator=g).half()
+        c = ops.gemm_f16(big, w, T, 256, W, bias=bias, resid=res)
+        for r0 in (0, T // 2 - 1000, T - 4096):
+            ref = big[r0:r0 + 4096].float() @ w.float().t() + bias.float() + res[r0:r0 + 4096].float()
+            assert torch.equal(c[r0:r0 + 4096].float(), ref), r0
+    elif layout == "km":                                 # data gradient: dx[T, 256] = dy[T, W] w[W, 256]
+        w = ints(W, 256, lo=-1, hi=2, seed=1)
+        c = ops.gemm_f16(big, w, T, 256, W, a_kmajor=True, b_kmajor=False)
+        for r0 in (0, T // 2 - 1000, T - 4096):
+            assert torch.equal(c[r0:r0 + 4096].float(), big[r0:r0 + 4096].float() @ w.float()), r0
+    else:                                                # weight gradient: dW[W, 256] = dy[T, W]^T x[T, 256], tokens = K
+        x = torch.randint(0, 2, (T, 256), device=DEV, dtype=torch.int8, generator=g).half()
+        big01 = (big != 0).half() * (torch.arange(T, device=DEV) % 7 == 0).half()[:, None]     # sums stay below 2048 * 32
+        c = ops.gemm_f16(big01, x, W, 256, T, a_kmajor=False, b_kmajor=False)
+        ref = torch.zeros(W, 256, device=DEV)
+        for r0 in range(0, T, 65536):
+            ref += big01[r0:r0 + 65536].float().t() @ x[r0:r0 + 65536].float()
+        assert float(ref.max()) < 60000
+        assert relerr(c, ref) < 1e-3 and torch.equal(c.float(), ref.half().float())
+
+
 @pytest.mark.parametrize("nseq,L,N,K", [(96, 50, 768, 768), (37, 10, 128, 512)])
 def test_gemm_strided_rows(nseq, L, N, K):
     """Row strides larger than the row length on A, C and the residual (the class-token rows of a [tokens, D] buffer,
