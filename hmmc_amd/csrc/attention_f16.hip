@@ -162,32 +162,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 //  * One 9 KiB LDS tile per wave, refilled from registers (K, then dO, then Q), serves the three transposed
 //    operands (ds_read_b64_tr_b16); per-query lse / delta are redistributed through 512 B of scratch.
 //  * Outputs leave as 16 B per lane: v_permlane16_swap pairs the d-tiles (2q, 2q+1) so a lane owns 8 consecutive d.
-// column sums over the 16 lanes c of a 16-lane row (every lane ends with the total)
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
-  return v;
-}
-// csum[dt][r] += the fp16-rounded value of acc[dt][r] (what the stored tensor holds)
-__device__ __forceinline__ void add_rounded(f4 (&csum)[4], const f4 (&acc)[4]) {
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) csum[dt][r] += (float)(half_t)acc[dt][r];
-}
-// dst[dt*16 + 4g + r] = sum over the 16 lanes c of csum[dt][r]
-__device__ __forceinline__ void store_colsum(float* dst, f4 (&csum)[4], int lane) {
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    f4 t;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = row16_sum(csum[dt][r]);
-    if ((lane & 15) == 0) *reinterpret_cast<f4*>(dst + dt * 16 + 4 * (lane >> 4)) = t;
-  }
-}
-
 template <int KT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = 16 * KT;
@@ -365,8 +339,7 @@ extern "C" int hmmc_attention_f16_bwd(const void* qkv, const void* out, const fl
   if (L > 64) {
     AttnArgs pl{};
     pl.qkv = (const half_t*)qkv; pl.out = (half_t*)out; pl.lse = (float*)lse; pl.dout = (const half_t*)dout;
-    pl.dqkv = (half_t*)dqkv; pl.nseq = nseq; pl.L = L; pl.H = H; pl.causal = causal;
-    if (dbias_partial) return HMMC_ERR_UNSUPPORTED;      // the long-sequence kernel has no fused bias partials
+    pl.dqkv = (half_t*)dqkv; pl.dbias = dbias_partial; pl.nseq = nseq; pl.L = L; pl.H = H; pl.causal = causal;
     return hmmc_attention_long_bwd(pl, stream);
   }
   AttnArgs p{};

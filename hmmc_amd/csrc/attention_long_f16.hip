@@ -168,6 +168,8 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
   half_t* scr = dtile + ROWS * LDS_STRIDE + wid * (16 * LDS_STRIDE);
   float* lse_s = reinterpret_cast<float*>(dtile + ROWS * LDS_STRIDE + NW * 16 * LDS_STRIDE);
   float* del_s = lse_s + ROWS;
+  float* red = del_s + ROWS;                     // [3][NW][64]: every wave's column sums of its dQ / dK / dV tiles
+  const bool want_dbias = p.dbias != nullptr;
   const int g = lane >> 4, c = lane & 15;
   const float* lse_g = p.lse + ((long)n * p.H + h) * L;
   // ---- operands -> LDS (thread -> row (tid >> 3) + RPP i, bytes 16 (tid & 7) .. +15; rows past L zero) and delta
@@ -205,6 +207,9 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
   const int nt = (L + 15) / 16;                  // 16-row tiles that hold a real token
   constexpr float C1 = 0.125f * LOG2E;
   // ---- phase 1: dQ
+  f4 csum[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) csum[dt] = f4{0.f, 0.f, 0.f, 0.f};
   for (int qt = wid; qt < nt; qt += NW) {
     const int qi = qt * 16 + c;
     h8 qf[2], df[2];
@@ -253,8 +258,13 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
                                                          cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[dt], 0, 0, 0);
     }
     store_rows(dq, ld, acc, qt * 16, L, scr, lane);
+    if (want_dbias) add_rounded(csum, acc);        // queries past L are exact zeros (their dS is)
   }
+  if (want_dbias) store_colsum(red + wid * 64, csum, lane);
   // ---- phase 2: dV and dK
+  f4 csk[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { csum[dt] = f4{0.f, 0.f, 0.f, 0.f}; csk[dt] = f4{0.f, 0.f, 0.f, 0.f}; }
   for (int kt = wid; kt < nt; kt += NW) {
     const int key = kt * 16 + c;
     const bool key_ok = key < L;
@@ -313,6 +323,20 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
     }
     store_rows(dv, ld, av, kt * 16, L, scr, lane);
     store_rows(dk, ld, ak, kt * 16, L, scr, lane);
+    if (want_dbias) { add_rounded(csum, av); add_rounded(csk, ak); }   // keys past L are exact zeros (P and dS are)
+  }
+  // in_proj bias-gradient partials of this (sequence, head): the waves' sums in wave order (fixed: bit-stable)
+  if (want_dbias) {
+    store_colsum(red + (1 * NW + wid) * 64, csk, lane);
+    store_colsum(red + (2 * NW + wid) * 64, csum, lane);
+    __syncthreads();
+    if (tid < 192) {
+      const int type = tid >> 6, d = tid & 63;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[(type * NW + w) * 64 + d];
+      p.dbias[(long)n * 3 * D + type * D + h * DH + d] = t;
+    }
   }
 }
 
@@ -349,7 +373,8 @@ int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream) {
 
 template <int KTL, int NW, bool CAUSAL>
 static void launch_long_bwd2(const AttnArgs& p, hipStream_t stream) {
-  constexpr int LDS = (4 * 16 * KTL + NW * 16) * LDS_STRIDE * 2 + 2 * 16 * KTL * 4;   // K, V, Q, dO + staging per wave + lse, delta
+  constexpr int LDS = (4 * 16 * KTL + NW * 16) * LDS_STRIDE * 2 + 2 * 16 * KTL * 4     // K, V, Q, dO + staging per wave + lse, delta
+                      + 3 * NW * 64 * 4;                                                // + the waves' column sums
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool done[HMMC_MAX_DEVICES] = {false};
   hmmc_allow_lds((const void*)attn_long_bwd_kernel<KTL, NW, CAUSAL>, LDS, done);

@@ -64,4 +64,30 @@ __device__ __forceinline__ void store_rows(half_t* dst, long ld, const f4 (&acc)
   }
 }
 
+// column sums over the 16 lanes c of a 16-lane row (every lane ends with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+// csum[dt][r] += the fp16-rounded value of acc[dt][r] (what the stored tensor holds)
+__device__ __forceinline__ void add_rounded(f4 (&csum)[4], const f4 (&acc)[4]) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) csum[dt][r] += (float)(half_t)acc[dt][r];
+}
+// dst[dt*16 + 4g + r] = sum over the 16 lanes c of csum[dt][r]
+__device__ __forceinline__ void store_colsum(float* dst, f4 (&csum)[4], int lane) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    f4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = row16_sum(csum[dt][r]);
+    if ((lane & 15) == 0) *reinterpret_cast<f4*>(dst + dt * 16 + 4 * (lane >> 4)) = t;
+  }
+}
+
 }  // namespace

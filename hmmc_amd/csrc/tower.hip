@@ -370,13 +370,10 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
     if (f32) {
       CK(hmmc_temporal_attention_bwd((const float*)a.qkv, a.stat, (const float*)dln, (float*)dqkv, nseq, L, heads, s));
       CK(hmmc_colsum(dqkv, G[3], (int)T, 3 * D, 3 * D, dt, dt, 0, workspace, gen, s));
-    } else if (L <= 64) {
+    } else {
       CK(hmmc_attention_f16_bwd(a.qkv, a.att, a.stat, dln, dqkv, p_attn, nseq, L, heads, causal, s));
       defer(p_attn, nseq, 3 * D, 3 * D, G[3], dt);
       (void)attn_bytes;
-    } else {
-      CK(hmmc_attention_f16_bwd(a.qkv, a.att, a.stat, dln, dqkv, nullptr, nseq, L, heads, causal, s));
-      CK(hmmc_colsum(dqkv, G[3], (int)T, 3 * D, 3 * D, dt, dt, 0, workspace, gen, s));
     }
     CK(side_wgrad(3, dqkv, a.ln1, G[2], 3 * D, D));
     CK(dgrad(f32, dqkv, P[2], dln, (int)T, 3 * D, D, nullptr, 0, s));

@@ -265,7 +265,7 @@ def attention_f16_fwd(qkv, nseq, L, H, causal):
 
 
 def attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=False):
-    """-> dqkv [, per-sequence column sums of dqkv: fp32 [nseq, 3*64*H] (L <= 64)]"""
+    """-> dqkv [, per-sequence column sums of dqkv: fp32 [nseq, 3*64*H] ]"""
     _chk(dout, torch.float16, "dout")
     dqkv = torch.empty_like(qkv)
     part = torch.empty((nseq, qkv.shape[1]), dtype=torch.float32, device=qkv.device) if want_dbias else None

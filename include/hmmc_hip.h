@@ -130,7 +130,7 @@ int hmmc_cast(const void* in, void* out, long n, int kind, hmmc_stream_t stream)
  * Replaces the attention core of nn.MultiheadAttention at modules/module_clip.py:251. */
 int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, int nseq, int L, int H, int causal,
                            hmmc_stream_t stream);
-/* dbias_partial (optional, fp32 [nseq][3*64*H], L <= 64 only): per-sequence column sums of dqkv, i.e. partial sums of
+/* dbias_partial (optional, fp32 [nseq][3*64*H]): per-sequence column sums of dqkv, i.e. partial sums of
  * the in-projection bias gradient; the caller finishes with hmmc_colsum over the nseq rows instead of re-reading dqkv. */
 int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
                            float* dbias_partial, int nseq, int L, int H, int causal, hmmc_stream_t stream);

@@ -24,6 +24,9 @@ rm -rf /tmp/prof_b32
 rocprofv3 --kernel-trace --stats -d /tmp/prof_b32 -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --batch 32 --steps 6 --warmup 2 --roofline-steps 0 --single-stream --vit-forward-iters 0 > $OUT/${TAG}_b32.log 2>&1
 cp $(find /tmp/prof_b32 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_b32_kernel_stats_single_stream.csv
 python3 $R/scratch/trace_gaps.py $(find /tmp/prof_b32 -name "*kernel_trace.csv" | head -1) 45 > $OUT/${TAG}_bench_b32_kernel_breakdown_single_stream.txt 2>&1
+rm -rf /tmp/prof_b32o
+rocprofv3 --kernel-trace --stats -d /tmp/prof_b32o -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --batch 32 --steps 6 --warmup 2 --roofline-steps 0 --vit-forward-iters 0 > $OUT/${TAG}_b32o.log 2>&1
+python3 $R/scratch/trace_gaps.py $(find /tmp/prof_b32o -name "*kernel_trace.csv" | head -1) 45 > $OUT/${TAG}_bench_b32_kernel_breakdown.txt 2>&1
 # HBM traffic of gemm_f16_kernel: separate passes per counter, kernel trace only
 CMD="--steps 2 --warmup 1 --no-cpu-baseline --roofline-steps 0 --vit-forward-iters 0"
 for c in FETCH_SIZE WRITE_SIZE; do

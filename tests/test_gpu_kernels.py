@@ -346,11 +346,11 @@ def test_attention_fwd_bwd(nseq, L, H, causal):
     for i, nm in enumerate("qkv"):
         e = relerr(d[:, i], g[:, i])
         assert e < 8e-3, f"d{nm} rel err {e}"
-    if L <= 64:                                   # fused in_proj bias-gradient partials: per-sequence column sums of dqkv
-        dqkv2, part = ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=True)
-        assert torch.equal(dqkv, dqkv2)
-        ref = dqkv.float().view(nseq, L, 3 * D).sum(1)
-        assert float((part - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-4
+    # fused in_proj bias-gradient partials: per-sequence column sums of dqkv (short and long kernels)
+    dqkv2, part = ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=True)
+    assert torch.equal(dqkv, dqkv2)
+    ref = dqkv.float().view(nseq, L, 3 * D).sum(1)
+    assert float((part - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-4
 
 
 def test_retrieval_rank_ties_and_targets():
