@@ -12,6 +12,11 @@ shapes = [("kk qkv  +b", "kk", T, 2304, 768, "b"), ("kk out  +b+r", "kk", T, 768
           ("km dfc", "km", T, 768, 3072, ""), ("km dproj *dgelu", "km", T, 3072, 768, "d"), ("km dqkv", "km", T, 768, 2304, ""), ("km dout", "km", T, 768, 768, ""),
           ("mm wqkv", "mm", 2304, 768, T, ""), ("mm wfc", "mm", 3072, 768, T, ""), ("mm wproj", "mm", 768, 3072, T, ""), ("mm wout", "mm", 768, 768, T, "")]
 g = torch.Generator(device="cuda").manual_seed(0)
+# the first case of a process measures low by up to 20 % (fresh allocations, clocks): run the first shape once, unmeasured, and
+# let the caching allocator hand the same blocks to the measured cases
+_a = torch.randn(T, 768, device="cuda", generator=g).half(); _w = torch.randn(2304, 768, device="cuda", generator=g).half(); _o = torch.empty(T, 2304, device="cuda", dtype=torch.float16)
+for _ in range(60): ops.gemm_f16(_a, _w, T, 2304, 768, out=_o)
+torch.cuda.synchronize(); del _a, _w, _o
 tot_f, tot_t = 0.0, 0.0
 for name, lay, M, N, K, epi in shapes:
     kw = {}
