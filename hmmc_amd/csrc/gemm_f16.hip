@@ -275,38 +275,54 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
 #pragma unroll
       for (int j = 0; j < 4; ++j) in[j] = unpack2(inr[i & 1][j][0], inr[i & 1][j][1]);
     }
-    // out / pre hold the fp32 values whose rounding to fp16 is the result (the pack below rounds exactly once)
-    f4 out[4], pre[4];
+    // pc / qc: the strip's result (and auxiliary result) as packed fp16, four 8-byte pieces in the MFMA layout
+    u2 pc[4], qc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f4 v = acc[i][j];
       if (flags & EPI_BIAS) v += bias[j];
       if (flags & EPI_QGELU) {
+        // QuickGELU with the reference's fp16 rounding points, two elements at a time.  The values that torch holds as
+        // fp16 tensors (h, t = 1.702 h, sigmoid(t), the product) stay PACKED: v_fma_mix_f32 reads either half as an fp32
+        // operand without a conversion, and the final product of two fp16 values is one v_pk_mul_f16 (exact product, one
+        // rounding: what the fp32 multiply + pack did).  15 VALU + 4 transcendental instructions per pair, against 33 + 4
+        // when every intermediate went through v_cvt_f32_f16 / v_cvt_f16_f32 (the epilogue is VALU-bound: c_fc forward
+        // ran 905 us against 610 us without an epilogue).
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float h = r16(v[r]);
-          const float t = r16s(1.702f * h);        // fp32 product, then fp16: torch's two roundings (see r16s)
-          const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
-          out[j][r] = h * r16(sg);                // product of two fp16 values: exact in fp32
+        for (int e = 0; e < 2; ++e) {
+          const unsigned hpk = pk2(v[2 * e], v[2 * e + 1]);                 // h = fp16(acc + bias)
+          float p0, p1, a0, a1;
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(p0) : "v"(hpk), "v"(1.702f));
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(p1) : "v"(hpk), "v"(1.702f));
+          const unsigned tpk = pk2(p0, p1);                                 // fp32 product, then fp16: torch's two roundings
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(a0) : "v"(tpk), "v"(-1.4426950408889634f));
+          asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(a1) : "v"(tpk), "v"(-1.4426950408889634f));
+          const float s0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a0));
+          const float s1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a1));
+          const unsigned spk = pk2(s0, s1);
+          unsigned opk;
+          asm("v_pk_mul_f16 %0, %1, %2" : "=v"(opk) : "v"(hpk), "v"(spk));
+          pc[j][e] = opk;
           // aux: the pre-activation h, or (EPI_SAVE_DGELU) QuickGELU'(h) = s + 1.702 h s (1 - s) so that the backward
           // GEMM multiplies by it (EPI_MULAUX) instead of evaluating exp and rcp again
-          pre[j][r] = (flags & EPI_SAVE_DGELU) ? __builtin_fmaf(1.702f * h * (1.0f - sg), sg, sg) : h;
+          qc[j][e] = (flags & EPI_SAVE_DGELU) ? pk2(__builtin_fmaf(p0 * (1.0f - s0), s0, s0), __builtin_fmaf(p1 * (1.0f - s1), s1, s1)) : hpk;
         }
-      } else if (flags & EPI_DGELU) {
+        continue;
+      }
+      f4 out;
+      if (flags & EPI_DGELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[j][r] = v[r] * qgelu_grad(in[j][r]);
+        for (int r = 0; r < 4; ++r) out[r] = v[r] * qgelu_grad(in[j][r]);
       } else if (flags & EPI_MULAUX) {
-        out[j] = v * in[j];
+        out = v * in[j];
       } else if (flags & EPI_RESID) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[j][r] = in[j][r] + r16(v[r]);
+        for (int r = 0; r < 4; ++r) out[r] = in[j][r] + r16(v[r]);
       } else {
-        out[j] = v;
+        out = v;
       }
+      pc[j] = u2{pk2(out[0], out[1]), pk2(out[2], out[3])};
     }
-    u2 pc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pc[j] = u2{pk2(out[j][0], out[j][1]), pk2(out[j][2], out[j][3])};
     if (want_csum) {                               // sums of the ROUNDED values, as a pass over the stored tensor would see
       const bool row_ok = FULL || m_base + 16 * i + c < p.M;
       if (row_ok) {
@@ -315,12 +331,7 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
       }
     }
     store_strip(p.C, i, pc);
-    if (two) {                                   // the pre-activation, for the backward pass
-      u2 qc[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) qc[j] = u2{pk2(pre[j][0], pre[j][1]), pk2(pre[j][2], pre[j][3])};
-      store_strip(p.aux_out, i, qc);
-    }
+    if (two) store_strip(p.aux_out, i, qc);      // the pre-activation or QuickGELU'(h), for the backward pass
   }
   flush();
   if (want_csum) {                               // 16 lanes c -> one partial row per wave: row block (m_base / (16 MT))
