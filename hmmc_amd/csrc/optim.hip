@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void enqueue_kernel(const float* __restrict__ 
 
 extern "C" int hmmc_mt_sumsq(const long* tab, const int* chunk, int nchunks, float* sumsq, int T, hipStream_t stream) {
   if (!tab || !chunk || !sumsq || nchunks <= 0 || T <= 0) return HMMC_ERR_ARG;
-  hipMemsetAsync(sumsq, 0, (size_t)T * sizeof(float), stream);
+  (void)hipMemsetAsync(sumsq, 0, (size_t)T * sizeof(float), stream);
   hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq);
   return hmmc_launch_status();
 }
@@ -261,7 +261,7 @@ extern "C" int hmmc_mt_sumsq(const long* tab, const int* chunk, int nchunks, flo
 extern "C" int hmmc_mt_clip_grad_norm(const long* tab, const int* chunk, int nchunks, float* sumsq, int T, float max_norm,
                                       float* out, hipStream_t stream) {
   if (!tab || !chunk || !sumsq || !out || nchunks <= 0 || T <= 0) return HMMC_ERR_ARG;
-  hipMemsetAsync(sumsq, 0, (size_t)T * sizeof(float), stream);
+  (void)hipMemsetAsync(sumsq, 0, (size_t)T * sizeof(float), stream);
   hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq);
   hipLaunchKernelGGL(mt_clip_coef_kernel, dim3(1), dim3(256), 0, stream, tab, (const float*)sumsq, T, max_norm, out);
   hipLaunchKernelGGL(mt_scale_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, (const float*)out);
@@ -275,7 +275,7 @@ extern "C" int hmmc_mt_bertadam(const long* tab, const float* groups_host, int n
   AdamGroups groups;
   for (int g = 0; g < ngroups; ++g)
     for (int j = 0; j < 8; ++j) groups.v[g][j] = groups_host[g * 8 + j];
-  hipMemsetAsync(sumsq, 0, (size_t)T * sizeof(float), stream);
+  (void)hipMemsetAsync(sumsq, 0, (size_t)T * sizeof(float), stream);
   hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq);
   hipLaunchKernelGGL(mt_bertadam_kernel, dim3(nchunks), dim3(256), 0, stream, tab, groups, chunk, (const float*)sumsq);
   return hmmc_launch_status();
