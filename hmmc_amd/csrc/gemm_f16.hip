@@ -26,7 +26,8 @@
 #include <cstdlib>
 
 #ifndef HMMC_DBG
-#define HMMC_DBG 0   // diagnostics (scratch/): 1 no global stores, 2 no epilogue (wrong results; timing only)
+#define HMMC_DBG 0   // diagnostics (scratch/): 1 no global stores, 2 no epilogue (wrong results; timing only);
+                     // 3 / 4 / 5: s_memrealtime stamps of the third work item into p.ws (scratch/gemm_stamps.py), 4 = 1 + stamps, 5 = 2 + stamps
 #endif
 
 namespace {
@@ -227,7 +228,7 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
   bool have_prev = false;
   auto flush = [&]() {
     if (!have_prev) return;
-#if HMMC_DBG == 1
+#if HMMC_DBG == 1 || HMMC_DBG == 4
     asm volatile("" :: "v"(pv0), "v"(pv1));
     return;
 #endif
@@ -428,6 +429,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
   int tm = tile / ntn, tn = tile - tm * ntn;
   int kt = split * p.ktps, kt_end = min(nkt, kt + p.ktps);     // host guarantees kt < kt_end for every item
   int buf = 0;
+#if HMMC_DBG >= 3
+  // 128 stamps per wave in two registers (v_writelane: stamp n lives in lane n), from the start of the wave's third item
+  unsigned st0 = 0, st1 = 0;
+  int sn = 0, items_done = 0;
+#define HMMC_STAMP() do { if (items_done >= 2 && sn < 128) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memrealtime(); \
+    st0 = (lane == sn) ? t_ : st0; st1 = (lane == sn - 64) ? t_ : st1; ++sn; } } while (0)
+#else
+#define HMMC_STAMP() do {} while (0)
+#endif
   if constexpr (MT != 8) {
     stage_tile<AK, BM, NTH>(ra, smem, wid, tid, tm * BM, kt * BKT, p.lda);
     stage_tile<BK, BN, NTH>(rb, smem + A_BYTES, wid, tid, tn * BN, kt * BKT, p.ldb);
@@ -448,7 +458,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
   // writes the finished tile and clears the accumulators for the next item (a zero C operand on the first K-tile
   // instead of the clear measured 1-5 % slower: it doubles the MFMA blocks of the main loop)
   auto finish_item = [&]() {
-#if HMMC_DBG == 2
+    HMMC_STAMP();
+#if HMMC_DBG == 2 || HMMC_DBG == 5
     _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(acc[i][j]));
 #else
     if (p.splitk > 1 || p.slab)
@@ -460,6 +471,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+#if HMMC_DBG >= 3
+    HMMC_STAMP();
+    ++items_done;
+#endif
   };
 
   if constexpr (MT == 8 && NT == 4) {
@@ -541,6 +556,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
       HMMC_BAR();
       HMMC_MM(0, 0, b0f);
       HMMC_BAR();
+      HMMC_STAMP();
       // phase 2
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -552,6 +568,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
       HMMC_BAR();
       HMMC_MM(0, 2, b1f);
       HMMC_BAR();
+      HMMC_STAMP();
       // phase 3
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -562,12 +579,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
       HMMC_BAR();
       HMMC_MM(4, 2, b1f);
       HMMC_BAR();
+      HMMC_STAMP();
       // phase 4
       stage_b(0);
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       HMMC_BAR();
       HMMC_MM(4, 0, b0f);
       HMMC_BAR();
+      HMMC_STAMP();
       int n_item, n_split, n_tm, n_tn, n_kt, n_end;
       next_pos(n_item, n_split, n_tm, n_tn, n_kt, n_end);
       if (kt + 1 >= kt_end) {
@@ -587,6 +606,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
 #undef HMMC_BAR
 #undef HMMC_MM
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing out-of-range DMA must land before the LDS is released
+#if HMMC_DBG >= 3
+    if (p.ws) {
+      unsigned* so = reinterpret_cast<unsigned*>(p.ws) + ((size_t)bid * 8 + wid) * 128;
+      so[lane] = st0; so[64 + lane] = st1;
+    }
+#endif
   } else {
     // ---- 128x128 tile, two workgroups per CU overlap each other: simple two-barrier loop
     while (true) {
