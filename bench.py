@@ -6,6 +6,7 @@ main_pretrain.py:213-245) on synthetic batches.  Default = BASELINE.json's headl
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python bench.py --mode pretrain --batch 128                       # SURVEY config 4 (FAM+VTM+FTM+MLM, MoCo K=1024)
+    python bench.py --mode eval --frames 24                           # eval leg at VATEX size: 15 000 x 1 500 x 24
     python bench.py --clip ViT-B/16 --frames 24 --batch 16            # one rank's share of SURVEY config 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -55,6 +56,79 @@ def task_config(**kw):
              warmup_proportion=0.1)
     d.update(kw)
     return Namespace(**d)
+
+
+def eval_leg(args, dev):
+    """The eval scorer over cached features (main_task_retrieval.py:321-357,512-513): queries x (video + F frames) logits,
+    mean of the top-k frame logits, one [queries, videos] matrix.  A step = one pass over all queries and videos."""
+    from hmmc_amd import ops
+    from hmmc_amd.modeling import BirdModel
+    F = args.frames
+    nq, nv = args.eval_queries, args.eval_videos
+    cfg = task_config(local_rank=0, rank=0, max_frames=F, pretrained_clip_name=args.clip)
+    torch.manual_seed(42)
+    model = BirdModel.from_pretrained("cross-base", state_dict=None, task_config=cfg).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(7)
+    E = 512
+    qs = [torch.randn(min(64, nq - s), E, generator=g, device=dev) for s in range(0, nq, 64)]          # loader batches
+    vs = [torch.randn(min(64, nv - s), E, generator=g, device=dev) for s in range(0, nv, 64)]
+    us = [torch.randn(min(64, nv - s), F, E, generator=g, device=dev) for s in range(0, nv, 64)]
+    for _ in range(args.warmup):
+        sim = model.eval_similarity(qs, vs, us)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim = model.eval_similarity(qs, vs, us)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    ops.raise_on_device_errors()
+    # the scorer alone, HIP events on the launch stream
+    packed = ops.eval_pack(torch.cat(vs).float().contiguous(), torch.cat(us).float().contiguous())
+    qn, _ = ops.l2norm_fwd(torch.cat(qs).float().contiguous())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    launches = 0
+    e0.record()
+    for _ in range(args.steps):
+        for s0 in range(0, nq, 4096):
+            ops.eval_score(qn[s0:s0 + 4096], packed, nv, F, model.top_frames, 100.0, want=("score",))
+            launches += 1
+    e1.record()
+    torch.cuda.synchronize()
+    us_launch = e0.elapsed_time(e1) * 1e3 / launches
+    flops = 2.0 * nq * nv * (F + 1) * E / (launches / args.steps)
+    slots = ops.eval_slots(F)
+    roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<..., TOPK> (exact-f32 MFMA scorer with the top-k epilogue)",
+            "achieved": round(flops / us_launch / 1e6, 1), "peak": 157.0, "unit": "TFLOP/s",
+            "frac": round(flops / us_launch / 1e6 / 157.0, 4), "traffic": None,
+            "avg_launch_us": round(us_launch, 1), "launches_per_step": launches // args.steps,
+            "note": f"useful FLOPs 2 nq nv (F+1) 512; the kernel multiplies {slots} slots per video (padding: x{slots / (F + 1):.2f}); "
+                    f"algorithmic HBM bytes {(nq * E + nv * (F + 1) * E + nq * nv) * 4 / 1e6:.0f} MB per step: not HBM-bound"}
+    out = {"metric": f"query-video pairs scored/sec, eval leg {nq} x {nv} x F={F} (top-{model.top_frames} frames)",
+           "value": round(nq * nv / dt, 1), "unit": "query-video pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": f"cached-feature retrieval scoring, {nq} queries x {nv} videos x {F} frames, 512-d fp32 features "
+                                  f"(concatenate + normalise + pack + score)", "mode": "eval"},
+           "roofline": roof, "checksum": round(float(sim.double().sum()), 3)}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, ROOT)
+        import oracle.hmmc_oracle as O
+        n_s = min(nq, 1500)
+        q, v, u = torch.cat(qs)[:n_s].cpu(), torch.cat(vs).cpu(), torch.cat(us).cpu()
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))     # as cpu_baseline()
+        ls = float(model.text_encoder.logit_scale)
+
+        def cpu_scores(qq):
+            sv = O.loose_similarity(qq, v, ls)
+            return sv + torch.topk(O.loose_similarity(qq, u, ls), k=model.top_frames, dim=2)[0].mean(dim=2)
+        cpu_scores(q[:64])
+        t0 = time.perf_counter()
+        ref = cpu_scores(q)
+        t = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(n_s * nv / t, 1), "unit": "query-video pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle eval_scores on {n_s} of the queries x {nv} videos x {F} frames, {t:.2f} s, {_cpu_model()}"}
+        out["max_abs_err_vs_oracle_sample"] = float((sim[:n_s] - ref.to(dev)).abs().max())
+    print(json.dumps(out), flush=True)
 
 
 def prep_optimizer(model, cfg, t_total):
@@ -163,7 +237,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=("finetune", "pretrain"), default="finetune",
+    ap.add_argument("--eval-queries", type=int, default=15000, help="--mode eval: captions (VATEX test: 1 500 videos x 10)")
+    ap.add_argument("--eval-videos", type=int, default=1500, help="--mode eval: candidate videos")
+    ap.add_argument("--mode", choices=("finetune", "pretrain", "eval"), default="finetune",
                     help="finetune: BirdModel (configs 2/3/5); pretrain: BirdPreTrainedModel, FAM+VTM+FTM+MLM, MoCo queues (config 4)")
     ap.add_argument("--batch", type=int, default=None, help="global batch (reference --batch_size); default 256 / 128 (pretrain)")
     ap.add_argument("--frames", type=int, default=12)
@@ -204,6 +280,11 @@ def main():
     from hmmc_amd import ops, synth
     from hmmc_amd.modeling import BirdModel, BirdPreTrainedModel
     from hmmc_amd.optimization import clip_grad_norm_
+
+    if args.mode == "eval":
+        if world > 1:
+            raise SystemExit("--mode eval scores cached features on one GPU (main_task_retrieval.py:321-357 runs it on rank 0)")
+        return eval_leg(args, dev)
 
     if args.reserve_cus is not None:
         os.environ["HMMC_RCCL_CUS"] = str(args.reserve_cus)
