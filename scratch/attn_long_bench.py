@@ -20,5 +20,6 @@ for L, H, causal in ((197, 12, False), (77, 8, True)):
         return e0.elapsed_time(e1) / n * 1e3
     tf = t(lambda: ops.attention_f16_fwd(qkv, nseq, L, H, causal))
     tb = t(lambda: ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal))
+    tbb = t(lambda: ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=True))
     fl = 2.0 * 2 * nseq * H * L * L * 64 * (0.5 if causal else 1.0)
-    print(f"L={L} H={H} causal={causal} nseq={nseq}: fwd {tf:8.1f} us ({fl/tf/1e6:6.1f} TF)   bwd {tb:8.1f} us ({2.5*fl/tb/1e6:6.1f} TF)")
+    print(f"L={L} H={H} causal={causal} nseq={nseq}: fwd {tf:8.1f} us ({fl/tf/1e6:6.1f} TF)   bwd {tb:8.1f} us ({2.5*fl/tb/1e6:6.1f} TF)   bwd + bias partials {tbb:8.1f} us")
