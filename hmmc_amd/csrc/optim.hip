@@ -32,9 +32,11 @@ __device__ __forceinline__ float block_sum(float v) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// sumsq[t] += sum of g^2 over this chunk (16-byte loads; the scalar loop only handles a tensor's ragged tail)
+// part[chunk] = sum of g^2 over this chunk (16-byte loads; the scalar loop only handles a tensor's ragged tail).  No
+// atomics: mt_sumsq_finish_kernel adds a tensor's chunks in a fixed order, so norms - and with them the clip coefficient
+// and every updated weight - are bit-identical from run to run.
 __global__ __launch_bounds__(256) void mt_sumsq_kernel(const long* __restrict__ tab, const int* __restrict__ chunk,
-                                                       float* __restrict__ sumsq) {
+                                                       float* __restrict__ part) {
   const int t = chunk[2 * blockIdx.x], ci = chunk[2 * blockIdx.x + 1];
   const long* e = tab + (long)t * 8;
   const long n = e[4];
@@ -59,7 +61,26 @@ __global__ __launch_bounds__(256) void mt_sumsq_kernel(const long* __restrict__ 
     for (long i = iv + threadIdx.x; i < i1; i += 256) { float x = g[i]; s += x * x; }
   }
   s = block_sum(s);
-  if (threadIdx.x == 0) atomicAdd(sumsq + t, s);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// sumsq[t] = sum of the partial sums of tensor t's chunks: chunks tab[t][7] .. + ceil(numel / CHUNK) - 1 of the list, lane l
+// takes chunks l, l + 64, ... in order, then a fixed butterfly.  One wave per tensor.
+__global__ __launch_bounds__(64) void mt_sumsq_finish_kernel(const long* __restrict__ tab, const int* __restrict__ chunk,
+                                                             int nchunks, const float* __restrict__ part, float* __restrict__ sumsq) {
+  const int t = blockIdx.x;
+  const long* e = tab + (long)t * 8;
+  const long first = e[7];
+  const long nch = (e[4] + CHUNK - 1) / CHUNK;
+  if (first < 0 || first + nch > nchunks || (nch > 0 && chunk[2 * first] != t)) {      // table without the first-chunk column
+    if (threadIdx.x == 0) sumsq[t] = __builtin_nanf("");
+    return;
+  }
+  float s = 0.f;
+  for (long c = threadIdx.x; c < nch; c += 64) s += part[first + c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (threadIdx.x == 0) sumsq[t] = s;
 }
 
 // out[0] = clip coefficient, out[1] = total norm (torch.nn.utils.clip_grad_norm_ semantics: per-tensor
@@ -252,8 +273,8 @@ __global__ __launch_bounds__(256) void enqueue_kernel(const float* __restrict__ 
 
 extern "C" int hmmc_mt_sumsq(const long* tab, const int* chunk, int nchunks, float* sumsq, int T, hipStream_t stream) {
   if (!tab || !chunk || !sumsq || nchunks <= 0 || T <= 0) return HMMC_ERR_ARG;
-  (void)hipMemsetAsync(sumsq, 0, (size_t)T * sizeof(float), stream);
-  hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq);
+  hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq + T);
+  hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq);
   return hmmc_launch_status();
 }
 
@@ -261,8 +282,8 @@ extern "C" int hmmc_mt_sumsq(const long* tab, const int* chunk, int nchunks, flo
 extern "C" int hmmc_mt_clip_grad_norm(const long* tab, const int* chunk, int nchunks, float* sumsq, int T, float max_norm,
                                       float* out, hipStream_t stream) {
   if (!tab || !chunk || !sumsq || !out || nchunks <= 0 || T <= 0) return HMMC_ERR_ARG;
-  (void)hipMemsetAsync(sumsq, 0, (size_t)T * sizeof(float), stream);
-  hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq);
+  hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq + T);
+  hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq);
   hipLaunchKernelGGL(mt_clip_coef_kernel, dim3(1), dim3(256), 0, stream, tab, (const float*)sumsq, T, max_norm, out);
   hipLaunchKernelGGL(mt_scale_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, (const float*)out);
   return hmmc_launch_status();
@@ -275,8 +296,8 @@ extern "C" int hmmc_mt_bertadam(const long* tab, const float* groups_host, int n
   AdamGroups groups;
   for (int g = 0; g < ngroups; ++g)
     for (int j = 0; j < 8; ++j) groups.v[g][j] = groups_host[g * 8 + j];
-  (void)hipMemsetAsync(sumsq, 0, (size_t)T * sizeof(float), stream);
-  hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq);
+  hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq + T);
+  hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq);
   hipLaunchKernelGGL(mt_bertadam_kernel, dim3(nchunks), dim3(256), 0, stream, tab, groups, chunk, (const float*)sumsq);
   return hmmc_launch_status();
 }

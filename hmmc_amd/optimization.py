@@ -65,11 +65,12 @@ class _TensorTable:
             tidx = np.repeat(np.arange(len(rows)), nch)
             cidx = np.concatenate([np.arange(n) for n in nch]) if len(rows) else np.zeros(0, dtype=np.int64)
             chunks = np.stack([tidx, cidx], axis=1).astype(np.int32)
+            arr[:, 7] = np.cumsum(nch) - nch            # index of the tensor's first chunk (the fixed-order norm reduction)
             self.tab = torch.from_numpy(arr).pin_memory().to(self.device, non_blocking=True)
             self.chunk = torch.from_numpy(chunks).pin_memory().to(self.device, non_blocking=True)
             self.nchunks = int(chunks.shape[0])
             self.T = len(rows)
-            self.sumsq = torch.zeros(len(rows), dtype=torch.float32, device=self.device)
+            self.sumsq = torch.zeros(len(rows) + self.nchunks, dtype=torch.float32, device=self.device)   # [T] norms + per-chunk partials
             self.key = key
         return self
 

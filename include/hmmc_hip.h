@@ -196,11 +196,13 @@ int hmmc_temporal_attention_fwd(const float* qkv, float* out, float* probs, int 
 int hmmc_temporal_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int b, int F, int H,
                                 hmmc_stream_t stream);
 
-/* Multi-tensor kernels.  tab: int64 [T][8] = {p, g, m, v device pointers, numel, dtype (0 fp16, 1 fp32), group, 0};
+/* Multi-tensor kernels.  tab: int64 [T][8] = {p, g, m, v device pointers, numel, dtype (0 fp16, 1 fp32), group,
+ * index of the tensor's first entry in `chunk`} (the chunk list is grouped by tensor, chunks ascending);
  * groups_host: HOST float [ngroups <= 32][8] = {scheduled lr, weight_decay, b1, b2, eps, max_grad_norm, 1-b1, 1-b2}, passed to the
  * kernel by value (tab[t][6] = group of tensor t): the per-step scalars need no device copy;
  * chunk: int32 [nchunks][2] = {tensor index, chunk index}, hmmc_mt_chunk_elems() elements per chunk;
- * sumsq: float [T] scratch. */
+ * sumsq: float [T + nchunks] scratch: per-chunk partial sums behind the T squared norms, which are formed by adding a tensor's
+ * chunks in list order - no atomics, so norms, clip coefficient and updated weights are bit-identical from run to run. */
 int hmmc_mt_chunk_elems(void);
 int hmmc_mt_sumsq(const long* tab, const int* chunk, int nchunks, float* sumsq, int T, hmmc_stream_t stream);
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) (main_task_retrieval.py:291): out[0] = coefficient, out[1] = total norm. */

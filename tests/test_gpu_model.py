@@ -523,3 +523,46 @@ def test_step_is_deterministic_across_runs_and_stream_modes():
     for n in g1:                     # every gradient, the token-embedding scatter included (owner rows, no atomics)
         assert torch.equal(g1[n], g2[n]), f"run-to-run difference in {n}"
         assert torch.equal(g1[n], g3[n]), f"overlap on/off difference in {n}"
+
+
+def test_training_steps_are_deterministic_including_the_updated_weights():
+    """Three optimizer steps (forward, backward, global clip, BertAdam) from identical state, repeated: losses and every
+    weight bit-identical from run to run and between the stream modes.  The norms behind the clip coefficient and the
+    per-parameter clip are sums over chunks of a tensor; with fp32 atomics their order, and with it every updated weight,
+    changed from run to run (found by scratch/soak_determinism.py; the single-step test above cannot see it)."""
+    import copy
+    from hmmc_amd.modeling import BirdModel
+    from hmmc_amd.optimization import clip_grad_norm_
+    import hmmc_amd.modeling as M
+    import hmmc_amd.functional as Fn2
+    cfg = task_config(max_frames=4, pretrained_clip_name="ViT-B/32")
+    model = BirdModel.from_pretrained("cross-base", state_dict=synth.finetune_state(synth.VIT_B32), task_config=cfg).to(DEV).train()
+    batch = [t.to(DEV) for t in synth.finetune_batch(8, 4, 32, tag="det3")]
+    sd0 = copy.deepcopy(model.state_dict())
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def run(overlap):
+        M._OVERLAP_TOWERS, Fn2._WGRAD_STREAM = overlap, overlap
+        model.load_state_dict(sd0)
+        opt = prep_optimizer(model, cfg, 50)
+        losses = []
+        for i in range(3):
+            loss = model(*batch, i + 1)
+            loss.backward()
+            clip_grad_norm_(params, 1.0)
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in params]
+
+    saved = (M._OVERLAP_TOWERS, Fn2._WGRAD_STREAM)
+    try:
+        ref_l, ref_w = run(False)
+        for overlap in (False, True, True, True, False, True):
+            l, w = run(overlap)
+            assert l == ref_l, (overlap, l, ref_l)
+            bad = [i for i, (a, b) in enumerate(zip(w, ref_w)) if not torch.equal(a, b)]
+            assert not bad, f"overlap={overlap}: {len(bad)} weight tensors differ from run to run"
+    finally:
+        M._OVERLAP_TOWERS, Fn2._WGRAD_STREAM = saved
