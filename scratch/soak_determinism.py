@@ -15,10 +15,11 @@ repeats = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 kind = sys.argv[3] if len(sys.argv) > 3 else "ft"
 dims = synth.VIT_B32
+SB, SF = int(os.environ.get("SOAK_B", "24")), int(os.environ.get("SOAK_F", "6"))
 if kind == "ft":
-    cfg = task_config(max_frames=6, pretrained_clip_name="ViT-B/32")
+    cfg = task_config(max_frames=SF, pretrained_clip_name="ViT-B/32")
     model = BirdModel.from_pretrained("cross-base", state_dict=synth.finetune_state(dims), task_config=cfg).to(DEV).train()
-    batch = [t.to(DEV) for t in synth.finetune_batch(24, 6, 32, tag="soak")]
+    batch = [t.to(DEV) for t in synth.finetune_batch(SB, SF, 32, tag="soak")]
     args = lambda i: (*batch, i)
 else:
     cfg = task_config(max_frames=4, pretrained_clip_name="ViT-B/32", dataset="chvtt", contrast_momentum=0.99, contrast_temperature=0.07,
