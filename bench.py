@@ -236,7 +236,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--eval-queries", type=int, default=15000, help="--mode eval: captions (VATEX test: 1 500 videos x 10)")
     ap.add_argument("--eval-videos", type=int, default=1500, help="--mode eval: candidate videos")
     ap.add_argument("--mode", choices=("finetune", "pretrain", "eval"), default="finetune",
