@@ -566,3 +566,33 @@ def test_training_steps_are_deterministic_including_the_updated_weights():
             assert not bad, f"overlap={overlap}: {len(bad)} weight tensors differ from run to run"
     finally:
         M._OVERLAP_TOWERS, Fn2._WGRAD_STREAM = saved
+
+
+@pytest.mark.parametrize("B,Fr,L", [(5, 3, 20), (2, 1, 32), (3, 7, 77), (7, 5, 9)])
+def test_model_vs_oracle_odd_shapes(B, Fr, L):
+    """Ragged sizes through the whole fine-tune path against the fp32 oracle: batch / frame counts that are not multiples of
+    any tile, one frame per video, and a 77-token text (the causal long-sequence attention kernel inside the text tower).
+    Loss within the as-written envelope, every gradient's direction (cosine >= 0.98)."""
+    dims = synth.TINY
+    model, sd = build(dims, max_frames=Fr)
+    batch = synth.finetune_batch(B, Fr, L, dims.image_res, tag=f"odd{B}.{Fr}.{L}")
+    ids, mask, vid, vf, idx = [t.to(DEV) for t in batch]
+    loss = model(ids, mask, vid, vf, idx, 1)
+    loss.backward()
+    sdo = {k: t.clone().requires_grad_(t.is_floating_point()) for k, t in sd.items()}
+    ref, _ = O.finetune_loss(batch[0], batch[2], sdo, mode="fp32")
+    ref.backward()
+    close(loss, ref, 3e-2, 3e-2, "loss")
+    worst = []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            assert sdo[n].grad is None or float(sdo[n].grad.abs().max()) == 0.0, n
+            continue
+        a, b = p.grad.float().cpu().flatten(), sdo[n].grad.flatten()
+        if float(b.norm()) < 1e-9:                      # e.g. frame position rows beyond Fr
+            assert float(a.norm()) < 1e-6, (n, float(a.norm()))
+            continue
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-20))
+        if cos < 0.98:
+            worst.append((n, cos, float(a.norm()), float(b.norm())))
+    assert not worst, f"gradient direction mismatches: {worst[:10]}"
