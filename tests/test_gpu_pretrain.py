@@ -218,3 +218,49 @@ def test_pretrain_gradients_vs_oracle():
         if cos < 0.97 or abs(ratio - 1) > 0.1:
             bad.append((n, round(cos, 4), round(ratio, 3), float(b.norm())))
     assert not bad, f"{len(bad)} gradients disagree with the oracle: {bad[:12]}"
+
+
+@pytest.mark.parametrize("kind", ["finetune", "pretrain"])
+def test_resume_from_checkpoint_is_bit_identical(kind):
+    """model + optimizer state saved after 3 steps (torch.save of the state_dicts, loaded with
+    weights_only=True into freshly built objects), 3 more steps: every tensor - weights, momentum encoders, queues,
+    queue_ptr, BatchNorm statistics, Adam moments - equals the uninterrupted run bit for bit."""
+    import io
+    from hmmc_amd.modeling import BirdModel, BirdPreTrainedModel
+    from hmmc_amd.optimization import clip_grad_norm_
+
+    def make():
+        if kind == "finetune":
+            cfg = task_config(max_frames=4)
+            m = BirdModel.from_pretrained("cross-base", state_dict=synth.finetune_state(synth.TINY), task_config=cfg)
+            batch = [t.to(DEV) for t in synth.finetune_batch(8, 4, 32, synth.TINY.image_res, tag="resume")]
+        else:
+            cfg = task_config(max_frames=4, dataset="chvtt", contrast_num_negative=16, lr=2e-3, text_lr=1e-3, coef_lr=0.5)
+            m = BirdPreTrainedModel.from_pretrained("cross-base", state_dict=synth.pretrain_state(synth.TINY, 16, 4), task_config=cfg)
+            batch = [t.to(DEV) for t in synth.pretrain_batch(4, 4, res=synth.TINY.image_res, tag="resume")]
+        m = m.to(DEV).train()
+        return m, prep_optimizer(m, cfg, 50), batch
+
+    def steps(m, opt, batch, lo, hi):
+        params = [p for p in m.parameters() if p.requires_grad]
+        for i in range(lo, hi):
+            torch.manual_seed(100 + i)                  # the MLM mask draws
+            m(*batch, i + 1).backward()
+            clip_grad_norm_(params, 1.0)
+            opt.step()
+            opt.zero_grad()
+
+    m, opt, batch = make()
+    steps(m, opt, batch, 0, 3)
+    buf = io.BytesIO()
+    torch.save({"model": m.state_dict(), "opt": opt.state_dict()}, buf)
+    steps(m, opt, batch, 3, 6)
+    ref = {k: v.clone() for k, v in m.state_dict().items()}
+    m2, opt2, batch2 = make()
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=True)
+    m2.load_state_dict(ck["model"])
+    opt2.load_state_dict(ck["opt"])
+    steps(m2, opt2, batch2, 3, 6)
+    bad = [k for k, v in m2.state_dict().items() if not torch.equal(v, ref[k])]
+    assert not bad, f"{len(bad)} tensors differ after the resume: {bad[:8]}"
