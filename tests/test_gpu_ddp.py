@@ -188,3 +188,45 @@ def test_rccl_one_rank_ddp_is_bit_identical():
     for n in g0:
         assert torch.equal(g0[n], g1[n]), f"{n}: DDP over RCCL changed the gradient"
         assert torch.equal(g1[n], g2[n]), f"{n}: not repeatable under DDP"
+
+
+# ----------------------------------------------------------------------------- several optimizer steps under DDP
+
+def _run_steps(rank, world, store, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
+    from hmmc_amd.modeling import BirdModel
+    from hmmc_amd.optimization import clip_grad_norm_
+    from test_gpu_model import prep_optimizer
+    torch.cuda.set_device(0)
+    cfg = task_config(rank=rank)
+    model = BirdModel.from_pretrained("cross-base", state_dict=synth.finetune_state(synth.TINY), task_config=cfg).cuda().train()
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True)     # as bench.py
+    opt = prep_optimizer(model, cfg, 20)
+    params = [p for p in model.parameters() if p.requires_grad]
+    B = 8
+    b = B // world
+    losses = []
+    for step in range(4):
+        ids, mask, vid, vf, idx = [t[rank * b:(rank + 1) * b].cuda() for t in synth.finetune_batch(B, 4, 32, tag=f"ddp.s{step}")]
+        loss = net(ids, mask, vid, vf, idx, step + 1)
+        loss.backward()
+        clip_grad_norm_(params, 1.0)
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    torch.save({"losses": losses, "weights": [p.detach().cpu() for p in params]}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_stay_identical_over_optimizer_steps():
+    """Four steps of forward / backward / clip / BertAdam under DDP (gradients as bucket views, the bench's configuration): both
+    ranks must hold bit-identical weights afterwards (same averaged gradients, deterministic norms and update) and see the
+    same global losses."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_run_steps, args=(2, os.path.join(d, "s"), d), nprocs=2, join=True)
+        a, b = [torch.load(os.path.join(d, f"s{r}.pt")) for r in range(2)]
+    assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+    bad = [i for i, (x, y) in enumerate(zip(a["weights"], b["weights"])) if not torch.equal(x, y)]
+    assert not bad, f"{len(bad)} parameter tensors differ between the ranks after 4 steps"
