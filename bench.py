@@ -435,7 +435,8 @@ def main():
                "step_tflops": round(value * per_pair_exec / 1e12, 1) if per_pair_exec else None,
                "step_tflops_reference_formulation": round(value * per_pair / 1e12, 1) if per_pair else None,
                "mfma_frac_whole_step": round(value * (per_pair_exec or per_pair) / 1e12 / (world * MFMA_PEAK_TFLOPS), 4) if per_pair else None,
-               "final_loss": round(final_loss, 4), "roofline": roof, "vit_forward": vit_forward}
+               "final_loss": round(final_loss, 4), "roofline": roof, "vit_forward": vit_forward,
+               "peak_device_memory_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(12, 32)
         print(json.dumps(out), flush=True)
