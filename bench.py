@@ -8,6 +8,7 @@ main_pretrain.py:213-245) on synthetic batches.  Default = BASELINE.json's headl
     python bench.py --mode pretrain --batch 128                       # SURVEY config 4 (FAM+VTM+FTM+MLM, MoCo K=1024)
     python bench.py --mode eval --frames 24                           # eval leg at VATEX size: 15 000 x 1 500 x 24
     python bench.py --clip ViT-B/16 --frames 24 --batch 16            # one rank's share of SURVEY config 5
+    python bench.py --gpus N --steps K --warmup W                     # starts its own N ranks (children, torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -262,12 +263,24 @@ def main():
     if args.batch is None:
         args.batch = 256 if args.mode == "finetune" else 128
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU under torch.distributed.run (the reference is
+        # launched the same way, README.md:83) as CHILD processes.  Nothing in this process has touched the GPU yet - and it
+        # never will: it only forwards the children's output and exit code (no exec of a GPU-initialised process).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     local_dev = local_rank % max(torch.cuda.device_count(), 1)      # rehearsal on fewer GPUs than ranks
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)

@@ -450,6 +450,7 @@ __global__ __launch_bounds__(TE_THREADS) void text_embed_bwd_kernel(const long* 
       __syncthreads();
       int next = rows;
       for (int base = start; base < rows; base += TE_THREADS) {
+        if (base + TE_THREADS - start > 65536) { next = base; break; }      // list entries are 16-bit offsets from `start` (block-uniform)
         const int t = base + tid;
         const bool hit = t < rows && ids[t] == my;
         const unsigned long long m = __ballot(hit);
@@ -715,7 +716,7 @@ extern "C" int hmmc_text_embed(const long* ids, const float* table, const float*
 extern "C" int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, long vocab,
                                    hipStream_t stream) {
   if (!ids || !dx || !dtable || rows <= 0 || vocab <= 0) return HMMC_ERR_ARG;
-  if (D % 8 || rows > 65535 + TE_THREADS) return HMMC_ERR_UNSUPPORTED;     // 16-bit row offsets within a batch of the list
+  if (D % 8 || rows > 0x7fffffffL) return HMMC_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(text_embed_bwd_kernel, dim3((unsigned)rows), dim3(TE_THREADS), 0, stream, ids, (const half_t*)dx, dtable,
                      (int)rows, D, vocab);
   return hmmc_launch_status();

@@ -259,10 +259,25 @@ class FinetuneHeadFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------- pre-training (MoCo) stages
 
+# HMMC_FORCE_COLLECTIVES=1: issue every collective of the path even in a process group of ONE rank (where each is the
+# identity and the product path normally skips it).  One GPU cannot host two RCCL ranks, so this is how the RCCL calls
+# themselves (all_gather_into_tensor / reduce_scatter_tensor / all_reduce on RCCL's stream, ordered against the tower
+# streams) are executed and checked bit-for-bit on a one-GPU box (tests/test_gpu_ddp.py).
+_FORCE_COLLECTIVES = os.environ.get("HMMC_FORCE_COLLECTIVES", "0") == "1"
+
+
+def collectives_active():
+    """True when the path's collectives must run: a process group of more than one rank (or the forcing switch above)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or _FORCE_COLLECTIVES
+
+
 def _sync_sum(t):
     """Sum a small statistics tensor over ranks (SyncBatchNorm's exchange, modules/modeling.py:115-129)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         t = t.contiguous()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
@@ -300,18 +315,13 @@ class MlpFn(torch.autograd.Function):
         # dgamma / dbeta are this rank's sums (DDP averages parameter gradients afterwards, as with SyncBatchNorm);
         # dx needs the sums over every rank's rows
         dbeta, dgamma = local[0].clone(), local[1].clone()
-        sums = _sync_sum(local.clone()) if _world() > 1 else local
+        sums = _sync_sum(local.clone()) if collectives_active() else local
         # sums / n on the device (n is the all-reduced row count): reading n on the host would stall the launch stream
         dh = ops.bn_bwd_apply(dy, y, h, mean, rstd, gamma, (sums / n).contiguous(), n_global=1.0)
         dw1 = ops.wgrad_f32(dh, x)
         db1 = ops.colsum(dh)
         dx = ops.dgrad_f32(dh, w1)
         return dx, dw1, db1, dgamma, dbeta, dw2, db2, None
-
-
-def _world():
-    import torch.distributed as dist
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 class MocoLossFn(torch.autograd.Function):

@@ -71,7 +71,7 @@ class _AllGatherCat(torch.autograd.Function):
 
 def dist_collect(x):
     """collect a tensor from all ranks: [b, ...] -> [b * world, ...] (rank order), differentiable."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not Fn.collectives_active():
         return x.contiguous()
     return _AllGatherCat.apply(x)
 
@@ -270,13 +270,16 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
         vocab = self.text_encoder.token_embedding.weight.shape[0]
         ids, labels = self.mask(ids, vocab, input_mask.device, targets=labels, probability_matrix=prob)
         hidden = self.text_encoder(ids, input_mask, return_hidden=True)
-        return self.calculate_mlm_loss(hidden, labels)
+        return self.calculate_mlm_loss(hidden, labels, _label_density=float(self.mlm_probability))
 
-    def calculate_mlm_loss(self, sequence_output_mlm, labels):
+    def calculate_mlm_loss(self, sequence_output_mlm, labels, _label_density=1.0):
+        """reference modules/modeling.py:171-179.  `_label_density` sizes the head's row buffer: get_mlm_loss passes the
+        Bernoulli rate its own mask() drew the labels with; labels from anywhere else (a direct call) may be dense, so
+        every position gets a row (1.0: no compaction limit, nothing can be dropped)."""
         c = self.cls
         return Fn.MlmHeadFn.apply(sequence_output_mlm, labels, c.transform.dense.weight, c.transform.dense.bias,
                                   c.transform.LayerNorm.weight, c.transform.LayerNorm.bias, c.decoder.weight, c.bias,
-                                  float(self.mlm_probability))
+                                  _label_density)
 
     def forward(self, video_data, video_frame, tag_ids, tag_mask, title_ids, title_mask, global_step):
         tag_ids = tag_ids.view(-1, tag_ids.shape[-1])
@@ -356,6 +359,11 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
         loss = self.weight_FAM * loss_FAM + self.weight_VTM * loss_VTM + self.weight_FTM * loss_FTM + self.weight_MLM * loss_MLM
         if self.rank == 0 and getattr(self.task_config, "logdir", None):
             self.task_config.writer.add_scalars("loss", {"loss": float(loss)}, global_step=global_step)
+        # device-side checks (token id outside the embedding table, MLM row buffer overflow) surface at the reference's own
+        # logging interval, where its loop reads the loss on the host anyway (main_pretrain.py:232-240)
+        nd = getattr(self.task_config, "n_display", 0)
+        if nd and global_step and global_step % nd == 0:
+            ops.raise_on_device_errors(video.device)
         return loss
 
     def loose_similarity(self, sequence_output, visual_output):
@@ -436,6 +444,16 @@ class BirdModel(BirdPreTrainedModel):
         self.text_encoder = TextEncoder(self.task_config, cross_config)
         self.visual_encoder = VisualEncoder(self.task_config, cross_config)
         self.loss_fct = CrossEn()
+
+    def frame_loss(self, query_output, frame_output):
+        """(1/F) sum_f [CrossEn(S_f) + CrossEn(S_f^T)], S_f = loose_similarity(query, frame[:, f, :]); differentiable
+        (reference modules/modeling.py:665-672).  forward() does not call it: there the same F terms are part of one fused
+        head together with the video-text term; this member evaluates them alone through the same kernels (the video
+        columns of the fused logit matrix are given weight 0 and a stand-in operand)."""
+        q = query_output.contiguous().float().view(-1, query_output.shape[-1])
+        u = frame_output.contiguous().float()
+        scale = min(math.exp(float(self.text_encoder.logit_scale)), 100.0)
+        return Fn.FinetuneHeadFn.apply(q, q.detach(), u, 0.0, 1.0, scale)
 
     def forward(self, query_ids, query_mask, video_data, video_frame, idx, global_step):
         query_ids = query_ids.view(-1, query_ids.shape[-1])

@@ -235,9 +235,14 @@ def text_embed_bwd(ids, dx, vocab):
 _ERR_FLAGS = {}
 
 
+def _device_key(device):
+    idx = torch.device(device).index
+    return idx if idx is not None else torch.cuda.current_device()      # a bare "cuda" means the current device, on every rank
+
+
 def device_error_flag(device):
     """int32 [1] on `device` that kernels set instead of faulting (token ids outside the embedding table)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = _device_key(device)
     if key not in _ERR_FLAGS:
         _ERR_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return _ERR_FLAGS[key]
@@ -245,7 +250,7 @@ def device_error_flag(device):
 
 def raise_on_device_errors(device=None):
     """Synchronising check of the device error flags (what nn.Embedding's IndexError is in the reference)."""
-    keys = list(_ERR_FLAGS) if device is None else [torch.device(device).index or 0]
+    keys = list(_ERR_FLAGS) if device is None else [_device_key(device)]
     for k in keys:
         f = _ERR_FLAGS.get(k)
         if f is not None and int(f.item()) != 0:

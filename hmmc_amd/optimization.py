@@ -118,19 +118,16 @@ def clip_grad_norm_(parameters, max_norm):
     tbl = _clip_tables.setdefault(str(dev), _TensorTable(dev))
     # per step only the gradient pointers can change (and in steady state the caching allocator hands the same ones back):
     # the static columns are kept with the table and the device copy is refreshed only when a pointer moved
-    ptrs = np.fromiter((g.data_ptr() for g in grads), dtype=np.int64, count=len(grads))
-    sig = (len(grads), sum(g.numel() for g in grads))
-    if getattr(tbl, "_sig", None) != sig:
-        for g in grads:
-            if not g.is_contiguous():
-                raise ValueError("gradients must be contiguous")
-        static = np.zeros((len(grads), 6), dtype=np.int64)
-        static[:, 4] = [g.numel() for g in grads]
-        static[:, 5] = [_dtype_flag(g) for g in grads]
-        tbl._static, tbl._sig = static, sig
-    static = tbl._static
-    rows = static.copy()
-    rows[:, 1] = ptrs
+    # The size and dtype columns are rebuilt from the gradients on EVERY call (a key of count and total size alone would
+    # let a different gradient set with the same totals - the same model after .float(), a second model - reuse stale sizes
+    # and dtypes: out-of-bounds reads); build() compares the whole table and uploads only what changed.
+    n = len(grads)
+    rows = np.zeros((n, 6), dtype=np.int64)
+    rows[:, 1] = np.fromiter((g.data_ptr() for g in grads), dtype=np.int64, count=n)
+    rows[:, 4] = np.fromiter((g.numel() for g in grads), dtype=np.int64, count=n)
+    rows[:, 5] = np.fromiter((_dtype_flag(g) for g in grads), dtype=np.int64, count=n)
+    if not all(g.is_contiguous() for g in grads):
+        raise ValueError("gradients must be contiguous")
     tbl.build(rows)
     out = torch.empty(2, dtype=torch.float32, device=dev)
     call("hmmc_mt_clip_grad_norm", ptr(tbl.tab), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T, float(max_norm), ptr(out))
@@ -164,11 +161,12 @@ class BertAdam(Optimizer):
     # rows: 2 ms of host time, which at small per-GPU batches is what the step waits for).  Once a full step has shown that
     # every parameter has a gradient and the parameters of a group share their step count, the static part of the table (weights,
     # moments, sizes, group index) is kept and a step only reads the gradient pointers and evaluates the schedule per group.
-    def _plan_fast_path(self, n_rows, n_hp_rows):
+    def _plan_fast_path(self, n_rows, steps_per_group):
+        """steps_per_group: {group index: set of the step counts its parameters had in the slow step just taken}."""
         self._fast = None
         groups = [g for g in self.param_groups if g["params"]]
         params = [p for g in groups for p in g["params"]]
-        if n_rows != len(params) or n_hp_rows != len(groups) or len(groups) > 32:
+        if n_rows != len(params) or len(groups) > 32 or any(len(s) != 1 for s in steps_per_group.values()):
             return                                   # some gradient was None, or a group's parameters differ in step count
         static = np.zeros((len(params), 7), dtype=np.int64)
         row = 0
@@ -186,14 +184,20 @@ class BertAdam(Optimizer):
             return False
         grads = [p.grad for p in fp["params"]]
         ps, static = fp["params"], fp["static"]
-        if (any(g is None for g in grads) or sum(len(g["params"]) for g in self.param_groups) != len(grads)
-                or any(ps[i].data_ptr() != static[i, 0] or self.state[ps[i]]["next_m"].data_ptr() != static[i, 2]
-                       for i in (0, len(ps) // 2, len(ps) - 1))):      # parameters moved / optimizer state reloaded
+        if any(g is None for g in grads) or sum(len(g["params"]) for g in self.param_groups) != len(grads):
+            self._fast = None
+            return False
+        # parameters moved / a moment tensor was replaced: every pointer is compared, as one array each
+        n = len(ps)
+        states = fp["states"]
+        if not (np.array_equal(np.fromiter((p.data_ptr() for p in ps), dtype=np.int64, count=n), static[:, 0])
+                and np.array_equal(np.fromiter((st["next_m"].data_ptr() for st in states), dtype=np.int64, count=n), static[:, 2])
+                and np.array_equal(np.fromiter((st["next_v"].data_ptr() for st in states), dtype=np.int64, count=n), static[:, 3])):
             self._fast = None
             return False
         hp = []
         for g in fp["groups"]:
-            steps = {self.state[p]["step"] for p in (g["params"][0], g["params"][-1])}
+            steps = {self.state[p]["step"] for p in g["params"]}
             if len(steps) != 1:
                 self._fast = None
                 return False
@@ -241,7 +245,7 @@ class BertAdam(Optimizer):
                 loss = closure()
         if self._fast_step():
             return loss
-        rows, frows = [], {}
+        rows, frows, group_steps = [], {}, {}
         dev = None
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
@@ -266,6 +270,7 @@ class BertAdam(Optimizer):
                 hp = (lr_s, group["weight_decay"], group["b1"], group["b2"], group["e"], group["max_grad_norm"],
                       1 - group["b1"], 1 - group["b2"])
                 gi_row = frows.setdefault(hp, len(frows))
+                group_steps.setdefault(gi, set()).add(state["step"])
                 rows.append((p.data_ptr(), p.grad.data_ptr(), state["next_m"].data_ptr(), state["next_v"].data_ptr(),
                              p.numel(), _dtype_flag(p), gi_row))
                 state["step"] += 1
@@ -273,7 +278,7 @@ class BertAdam(Optimizer):
             return loss
         if dev.type != "cuda":
             raise RuntimeError("hmmc_amd.BertAdam runs on the GPU only (no CPU fallback)")
-        self._plan_fast_path(len(rows), len(frows))
+        self._plan_fast_path(len(rows), group_steps)
         if self._table is None:
             self._table = {}
         hps = list(frows)                                   # insertion order = row index

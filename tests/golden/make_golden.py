@@ -307,6 +307,32 @@ def fx_enc_b32(mclip, mmodel, mopt, mmetrics):
     _enc_fixture(mclip, mmodel, "enc_b32", synth.VIT_B32, 2, 2, 32, ("fp32", "aswritten"))
 
 
+def fx_enc_b16(mclip, mmodel, mopt, mmetrics):
+    """True ViT-B/16 dimensions (197 tokens per frame, 12 heads: SURVEY config 5's attention path).  Two videos of two
+    frames: with one video the 1 x 1 InfoNCE is identically zero and no gradient would be pinned."""
+    _enc_fixture(mclip, mmodel, "enc_b16", synth.VIT_B16, 2, 2, 32, ("fp32", "aswritten"))
+
+
+def fx_enc_b32x8(mclip, mmodel, mopt, mmetrics):
+    """True ViT-B/32 dimensions on a batch whose 8 x 8 score matrices can reorder: features, the similarity of
+    modeling.py:207-229 and the eval score S_video + mean top-k frame logits (main_task_retrieval.py:332-336) in BOTH
+    regimes of the reference, so the GPU test can assert the reference's own fp16-vs-fp32 envelope at real width."""
+    dims, B, Fr, L, k = synth.VIT_B32, 8, 4, 32, 2
+    sd = synth.finetune_state(dims)
+    ids, mask, vid, vf, idx = synth.finetune_batch(B, Fr, L, dims.image_res, tag="enc_b32x8")
+    for mode in ("fp32", "aswritten"):
+        model, _ = build_reference_model(mclip, mmodel.BirdModel, dims, sd, mode, max_frames=Fr)
+        with torch.no_grad():
+            q = model.text_encoder(ids, mask)
+            v, u = model.visual_encoder(vid, vf)
+            sv = model.loose_similarity(q, v)
+            sf = model.loose_similarity(q, u)
+            fk = torch.topk(sf, k=k, dim=2)[0].mean(dim=2)
+            loss = model(ids, mask, vid, vf, idx, 1)
+        save(f"enc_b32x8_{mode}", dims=json.dumps(dims.to_dict()), B=B, F=Fr, L=L, k=k, text_feat=q, video_emb=v, frame_output=u,
+             S_video=sv, S_frame_topk=fk, loss=loss)
+
+
 def fx_bertadam(mclip, mmodel, mopt, mmetrics):
     out = {}
     specs = [("a32", (37,), torch.float32, 0.2, 1e-4, 3.0), ("b32", (8, 9), torch.float32, 0.0, 3e-5, 0.01),
@@ -474,6 +500,7 @@ def fx_manifest(mclip, mmodel, mopt, mmetrics):
 
 
 FIXTURES = {"manifest": fx_manifest, "head": fx_head, "enc_tiny": fx_enc_tiny, "enc_rank": fx_enc_rank, "multisent": fx_multisent, "frame_sampling": fx_frame_sampling, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
+            "enc_b16": fx_enc_b16, "enc_b32x8": fx_enc_b32x8,
             "bertadam": fx_bertadam, "train_ft": fx_train_ft, "moco": fx_moco}
 
 

@@ -230,3 +230,131 @@ def test_two_ranks_stay_identical_over_optimizer_steps():
     assert a["losses"] == b["losses"], (a["losses"], b["losses"])
     bad = [i for i, (x, y) in enumerate(zip(a["weights"], b["weights"])) if not torch.equal(x, y)]
     assert not bad, f"{len(bad)} parameter tensors differ between the ranks after 4 steps"
+
+
+# ----------------------------------------------------------------------------- the path's own RCCL collectives, one rank
+
+def _run_rccl_collectives(rank, out_dir, port):
+    """Every collective the product path issues, on the nccl backend (RCCL), in a process group of one rank with the
+    world-size-1 shortcut switched off (hmmc_amd.functional._FORCE_COLLECTIVES): all_gather_into_tensor and its
+    reduce_scatter_tensor backward (dist_collect, reference modules/modeling.py:25-36,698-700), the packed key gather of the
+    enqueue (:249-258) and the SyncBatchNorm all-reduces (:115-129).  With one rank each is the identity, so the forced run
+    must reproduce the unforced one bit for bit - what is exercised is that the calls are accepted by RCCL with these
+    tensors, run on its stream, and are ordered correctly against the tower / side / weight-gradient streams."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import hmmc_amd.functional as Fn
+    import hmmc_amd.modeling as M
+    from conftest import golden
+    torch.cuda.set_device(0)
+    res = {}
+    Fn._FORCE_COLLECTIVES = True
+    assert Fn.collectives_active() and M._AllGatherCat._flat()
+    # (1) the differentiable all-gather itself
+    x = torch.randn(6, 14 * 512, device="cuda", requires_grad=True)
+    y = M._AllGatherCat.apply(x * 1.0)
+    g = torch.randn_like(y)
+    y.backward(g)
+    torch.cuda.synchronize()
+    res["gather_fwd"], res["gather_bwd"] = bool(torch.equal(y, x)), bool(torch.equal(x.grad, g))
+    yc = M.dist_collect(x.detach())
+    res["collect"] = bool(torch.equal(yc, x)) and yc.data_ptr() != x.data_ptr()      # went through the collective, not the shortcut
+    # (2) SyncBatchNorm's sum
+    t = torch.randn(2 * 4096 + 1, device="cuda")
+    res["sync_sum"] = bool(torch.equal(Fn._sync_sum(t.clone()), t))
+
+    # (3) fine-tune and (4) pre-train steps, forced vs not
+    def finetune(force):
+        Fn._FORCE_COLLECTIVES = force
+        model = M.BirdModel.from_pretrained("cross-base", state_dict=synth.finetune_state(synth.TINY),
+                                            task_config=task_config(max_frames=6)).cuda().train()
+        batch = [t.cuda() for t in synth.finetune_batch(16, 6, 32, tag="det")]
+        loss = model(*batch, 1)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    def pretrain(force):
+        Fn._FORCE_COLLECTIVES = force
+        gm = golden("moco_aswritten")
+        K, B, Fr = int(gm["K"]), int(gm["B"]), int(gm["F"])
+        cfg = task_config(contrast_num_negative=K, max_frames=Fr, dataset="chvtt")
+        model = M.BirdPreTrainedModel.from_pretrained("cross-base", state_dict=synth.pretrain_state(synth.TINY, K, Fr),
+                                                      task_config=cfg).cuda().train()
+        out = []
+        for step in range(2):
+            model._mlm_draws = [torch.from_numpy(gm[f"mlm_{n}{step}"]) for n in ("masked", "replaced", "randsel", "words")]
+            loss = model(*[t.cuda() for t in synth.pretrain_batch(B, Fr, tag=f"moco.s{step}")], step + 1)
+            model.zero_grad(set_to_none=True)
+            loss.backward()
+            out.append(float(loss))
+        torch.cuda.synchronize()
+        S = model.state_dict()
+        return out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, \
+            {k: S[k].clone() for k in PT_BUFFERS}
+
+    calls = {"n": 0}
+    for name in ("all_gather_into_tensor", "reduce_scatter_tensor", "all_reduce"):
+        orig = getattr(dist, name)
+
+        def counted(*a, _o=orig, _n=name, **k):
+            calls[_n] = calls.get(_n, 0) + 1
+            return _o(*a, **k)
+        setattr(dist, name, counted)
+    l0, g0 = finetune(False)
+    assert not calls.get("all_gather_into_tensor")
+    l1, g1 = finetune(True)
+    res["ft_calls"] = (calls.get("all_gather_into_tensor", 0), calls.get("reduce_scatter_tensor", 0))
+    res["ft_loss"] = (l0, l1)
+    res["ft_bad"] = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+    calls.clear()
+    p0 = pretrain(False)
+    assert not calls.get("all_gather_into_tensor") and not calls.get("all_reduce")
+    p1 = pretrain(True)
+    res["pt_calls"] = (calls.get("all_gather_into_tensor", 0), calls.get("all_reduce", 0))
+    res["pt_loss"] = (p0[0], p1[0])
+    res["pt_bad"] = [n for n in p0[1] if not torch.equal(p0[1][n], p1[1][n])] + [k for k in p0[2] if not torch.equal(p0[2][k], p1[2][k])]
+    torch.save(res, os.path.join(out_dir, "rccl_coll.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_of_the_path_execute_and_are_exact():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_run_rccl_collectives, args=(d, port), nprocs=1, join=True)
+        r = torch.load(os.path.join(d, "rccl_coll.pt"))
+    assert r["gather_fwd"] and r["gather_bwd"] and r["collect"] and r["sync_sum"], r
+    assert r["ft_calls"] == (1, 1), r["ft_calls"]                 # one packed all-gather forward, one reduce-scatter backward
+    assert r["ft_loss"][0] == r["ft_loss"][1] and not r["ft_bad"], (r["ft_loss"], r["ft_bad"][:5])
+    # per pre-train step: one packed key gather; SyncBN: 3 forward sums (v_projector, v_predictor, v_projector_k) + 2 backward
+    assert r["pt_calls"][0] == 2 and r["pt_calls"][1] == 2 * 5, r["pt_calls"]
+    assert r["pt_loss"][0] == r["pt_loss"][1] and not r["pt_bad"], (r["pt_loss"], r["pt_bad"][:5])
+
+
+# ----------------------------------------------------------------------------- bench.py starts its own ranks
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver starts the N = 1 run) must start two ranks
+    itself, as children, and print ONE JSON line from rank 0.  Rehearsed here on the one GPU over gloo (RCCL refuses two
+    ranks on one device); the code path - self-launch, rendezvous on 127.0.0.1, DDP wrap, barriers, max-over-ranks timing,
+    roofline steps - is the one the 8-GPU run takes (reference launch: README.md:83, main_task_retrieval.py:207-208)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HMMC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "8", "--frames", "4", "--steps", "2",
+                        "--warmup", "1", "--roofline-steps", "1", "--vit-forward-iters", "1", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["per_gpu_batch"] == 4
+    assert out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["final_loss"] == out["final_loss"] and abs(out["final_loss"]) < 50       # finite
+    assert out["config"]["gemm_reserved_cus"] == 16 and out["roofline"]["launches_per_step"] > 0

@@ -297,6 +297,17 @@ def test_colsum_patchify_embed():
     ref2 = torch.zeros(1000, 512, device=DEV, dtype=torch.float64).index_add_(0, ids2.view(-1), dx2.double())
     assert relerr(dt2, ref2.float()) < 1e-5
     assert torch.equal(dt2, ops.text_embed_bwd(ids2, dx2, 1000))
+    # more rows than a 16-bit offset spans (a list batch ends where `t - start` would pass 65 535): 65 536 and 66 000 rows
+    # truncated offsets in round 2's kernel; heavy hitters in the first and in the last rows
+    for nrows in (65536, 66000, 140000):
+        ids3 = torch.randint(0, 300, (nrows,), device=DEV)
+        ids3[::7] = 0
+        ids3[-5:] = 299
+        ids3[:3] = 299
+        dx3 = rnd(nrows, 128, seed=13)
+        dt3 = ops.text_embed_bwd(ids3.view(-1, 1), dx3, 300)
+        ref3 = torch.zeros(300, 128, device=DEV, dtype=torch.float64).index_add_(0, ids3, dx3.double())
+        assert relerr(dt3, ref3.float()) < 1e-5, nrows
     # ids outside the table: no fault, zero row + position embedding, flag raised on the host check, no gradient
     bad = ids.clone()
     bad[0, 3], bad[2, 5] = 1000, -7
@@ -329,7 +340,8 @@ def attn_ref(qkv, nseq, L, H, causal):
 
 @pytest.mark.parametrize("nseq,L,H,causal", [(5, 50, 2, False), (3, 32, 8, True), (2, 45, 2, True), (7, 25, 2, True),
                                              (4, 64, 12, False), (3, 17, 2, False), (3, 197, 2, False), (2, 77, 8, True),
-                                             (2, 130, 2, True), (1, 256, 1, False)])
+                                             (2, 130, 2, True), (1, 256, 1, False),
+                                             (5, 197, 12, False)])      # ViT-B/16's real shape: 197 tokens x 12 heads
 def test_attention_fwd_bwd(nseq, L, H, causal):
     D = H * 64
     qkv = rnd(nseq * L, 3 * D, scale=1.0)

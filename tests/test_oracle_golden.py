@@ -66,7 +66,8 @@ def test_eval_scorer_and_metrics():
 ENC = [("enc_tiny", "fp32", synth.TINY, True), ("enc_tiny", "aswritten", synth.TINY, True),
        ("enc_tiny_notemp", "fp32", synth.TINY, False),
        ("enc_tiny16", "fp32", synth.TINY16, True), ("enc_tiny16", "aswritten", synth.TINY16, True),
-       ("enc_b32", "fp32", synth.VIT_B32, True), ("enc_b32", "aswritten", synth.VIT_B32, True)]
+       ("enc_b32", "fp32", synth.VIT_B32, True), ("enc_b32", "aswritten", synth.VIT_B32, True),
+       ("enc_b16", "fp32", synth.VIT_B16, True)]          # true ViT-B/16 dims (197 tokens x 12 heads)
 
 
 @pytest.mark.parametrize("name,mode,dims,use_temp", ENC)
@@ -104,6 +105,27 @@ def test_encoders_and_loss(name, mode, dims, use_temp):
         tg = sd["text_encoder.token_embedding.weight"].grad
         close(tg[synth.SOT, :8], g["g:text_encoder.token_embedding.weight[SOT]"], 1e-6, 2e-3, "tok SOT")
         close(tg[synth.EOT, :8], g["g:text_encoder.token_embedding.weight[EOT]"], 1e-6, 2e-3, "tok EOT")
+
+
+def test_encoders_b32x8_scores():
+    """The 8 x 8 retrieval problem at true ViT-B/32 dims (fp32 regime): features, x100 logits and the mean top-k frame
+    logits of the oracle against the reference's, and identical argsort of every row."""
+    g = golden("enc_b32x8_fp32")
+    dims = synth.VIT_B32
+    B, Fr, L, k = int(g["B"]), int(g["F"]), int(g["L"]), int(g["k"])
+    sd = synth.finetune_state(dims)
+    ids, mask, vid, vf, idx = synth.finetune_batch(B, Fr, L, dims.image_res, tag="enc_b32x8")
+    with torch.no_grad():
+        loss, (q, v, u) = O.finetune_loss(ids, vid, sd, mode="fp32")
+        sv, fk = O.eval_scores(q, v, u, k)
+    close(q, g["text_feat"], 2e-4, 2e-4, "text_feat")
+    close(u, g["frame_output"], 2e-4, 2e-4, "frame_output")
+    close(v, g["video_emb"], 2e-4, 2e-4, "video_emb")
+    close(sv, g["S_video"], 1e-3, what="S_video (1e-3 logits)")
+    close(fk, g["S_frame_topk"], 1e-3, what="top-k frame logits")
+    close(loss, g["loss"], 1e-4, what="loss")
+    assert np.array_equal(np.argsort(-sv.numpy(), 1), np.argsort(-g["S_video"], 1))
+    assert np.array_equal(np.argsort(-(sv + fk).numpy(), 1), np.argsort(-(g["S_video"] + g["S_frame_topk"]), 1))
 
 
 BERTADAM_SPECS = [("a32", (37,), torch.float32, 0.2, 1e-4, 3.0), ("b32", (8, 9), torch.float32, 0.0, 3e-5, 0.01),
