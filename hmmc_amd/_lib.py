@@ -31,11 +31,11 @@ SIGNATURES = {
     "hmmc_multi_colreduce": ("pip", "i"),
     "hmmc_colsum_workspace": ("ii", "z"),
     "hmmc_colsum": ("ppiiliiipzp", "i"),
-    "hmmc_patchify_u8": ("pppiiiippp", "i"),
-    "hmmc_patchify": ("ppiiiip", "i"),
-    "hmmc_vit_embed": ("pppliip", "i"),
-    "hmmc_text_embed": ("ppppliilpp", "i"),
-    "hmmc_text_embed_bwd": ("ppplilp", "i"),
+    "hmmc_patchify_u8": ("pppiiiippip", "i"),
+    "hmmc_patchify": ("ppiiiiip", "i"),
+    "hmmc_vit_embed": ("pppliiip", "i"),
+    "hmmc_text_embed": ("ppppliilpip", "i"),
+    "hmmc_text_embed_bwd": ("ppplilip", "i"),
     "hmmc_cast": ("pplip", "i"),
     "hmmc_attention_f16_fwd": ("pppiiiip", "i"),
     "hmmc_attention_f16_bwd": ("ppppppiiiip", "i"),

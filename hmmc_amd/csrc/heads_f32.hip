@@ -302,6 +302,110 @@ __global__ __launch_bounds__(64) void tattn_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------- fp32 attention for 65..256 tokens (the CLIP towers in the
+// reference's fp32-upcast regime, model.float(): ViT-B/16 has 197 tokens, the text tower up to 77).  Exact fp32 arithmetic,
+// probabilities saved like the short kernel's; a parity path, not a fast one.  One 256-thread workgroup per (sequence, head):
+// K and V in LDS ([L][65] floats: a lane per key row or per feature, both conflict-free), a wave per query row.
+constexpr int GA_MAXL = 256;
+__global__ __launch_bounds__(256) void gattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                        float* __restrict__ probs, int L, int H, int causal) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int D = H * 64;
+  float* k = sm; float* v = k + L * 65; float* prow = v + L * 65;            // prow: [4][GA_MAXL], qrow: [4][64]
+  float* qrow = prow + 4 * GA_MAXL;
+  for (int idx = threadIdx.x; idx < L * 64; idx += 256) {
+    const int f = idx >> 6, d = idx & 63;
+    const float* base = qkv + ((long)b * L + f) * 3 * D + hd * 64 + d;
+    k[f * 65 + d] = base[D];
+    v[f * 65 + d] = base[2 * D];
+  }
+  __syncthreads();
+  float* pw = prow + w * GA_MAXL;
+  float* qw = qrow + w * 64;
+  float* pg = probs + ((long)b * H + hd) * L * L;
+  for (int i = w; i < L; i += 4) {
+    qw[lane] = qkv[((long)b * L + i) * 3 * D + hd * 64 + lane] * 0.125f;
+    float sc[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = lane + 64 * t;
+      float s = -INFINITY;
+      if (j < L && !(causal && j > i)) {
+        s = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) s += qw[d] * k[j * 65 + d];
+      }
+      sc[t] = s;
+      m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { sc[t] = (sc[t] == -INFINITY) ? 0.f : __expf(sc[t] - m); sum += sc[t]; }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = lane + 64 * t;
+      if (j < L) { const float pj = sc[t] * inv; pw[j] = pj; pg[(long)i * L + j] = pj; }
+    }
+    float o = 0.f;
+    for (int j = 0; j < L; ++j) o += pw[j] * v[j * 65 + lane];
+    out[((long)b * L + i) * D + hd * 64 + lane] = o;
+  }
+}
+
+// dV[j] = sum_i P[i][j] dO[i];  dP[i][j] = <dO[i], V[j]>;  dS = P o (dP - rowsum(P o dP));  dQ[i] = sum_j dS[i][j] K[j] / 8;
+// dK[j] = sum_i dS[i][j] Q[i] / 8.  Pass A: a wave per query row (dQ, and delta[i] = rowsum(P o dP) into LDS); pass B: a wave
+// per key row (dK, dV) re-forming dP[i][j] by a wave reduction.  No atomics: every output element has one owner.
+__global__ __launch_bounds__(256) void gattn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
+                                                        const float* __restrict__ dout, float* __restrict__ dqkv, int L, int H) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int D = H * 64;
+  float* k = sm; float* v = k + L * 65; float* drow = v + L * 65;            // drow: [4][GA_MAXL] dS of a row; delta: [GA_MAXL]
+  float* delta = drow + 4 * GA_MAXL;
+  for (int idx = threadIdx.x; idx < L * 64; idx += 256) {
+    const int f = idx >> 6, d = idx & 63;
+    const float* base = qkv + ((long)b * L + f) * 3 * D + hd * 64 + d;
+    k[f * 65 + d] = base[D];
+    v[f * 65 + d] = base[2 * D];
+  }
+  __syncthreads();
+  const float* pg = probs + ((long)b * H + hd) * L * L;
+  float* dw = drow + w * GA_MAXL;
+  for (int i = w; i < L; i += 4) {
+    const float dO = dout[((long)b * L + i) * D + hd * 64 + lane];
+    float dot = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float dp = wave_sum(dO * v[j * 65 + lane]);
+      if (lane == 0) dw[j] = dp;
+      dot += pg[(long)i * L + j] * dp;
+    }
+    if (lane == 0) delta[i] = dot;
+    float dq = 0.f;
+    for (int j = 0; j < L; ++j) dq += pg[(long)i * L + j] * (dw[j] - dot) * k[j * 65 + lane];
+    dqkv[((long)b * L + i) * 3 * D + hd * 64 + lane] = dq * 0.125f;
+  }
+  __syncthreads();
+  for (int j = w; j < L; j += 4) {
+    const float vj = v[j * 65 + lane];
+    float dk = 0.f, dv = 0.f;
+    for (int i = 0; i < L; ++i) {
+      const float dO = dout[((long)b * L + i) * D + hd * 64 + lane];
+      const float q = qkv[((long)b * L + i) * 3 * D + hd * 64 + lane];
+      const float pij = pg[(long)i * L + j];
+      const float dp = wave_sum(dO * vj);
+      dv += pij * dO;
+      dk += pij * (dp - delta[i]) * q;
+    }
+    float* o = dqkv + ((long)b * L + j) * 3 * D + hd * 64 + lane;
+    o[D] = dk * 0.125f;
+    o[2 * D] = dv;
+  }
+}
+
 inline int nblk(long work, int cap = 4096) {
   long b = (work + 255) / 256;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -420,7 +524,15 @@ extern "C" int hmmc_add_rowbias(const float* x, const float* table, float* out, 
 
 extern "C" int hmmc_temporal_attention_fwd(const float* qkv, float* out, float* probs, int b, int F, int H, int causal,
                                            hipStream_t stream) {
-  if (!qkv || !out || !probs || b <= 0 || F <= 0 || F > 64 || H <= 0) return HMMC_ERR_ARG;
+  if (!qkv || !out || !probs || b <= 0 || F <= 0 || H <= 0) return HMMC_ERR_ARG;
+  if (F > GA_MAXL) return HMMC_ERR_UNSUPPORTED;
+  if (F > 64) {                                  // the CLIP towers' token counts in the fp32 regime (parity path)
+    size_t gl = (size_t)(2 * F * 65 + 4 * GA_MAXL + 4 * 64) * sizeof(float);
+    static bool gdone[HMMC_MAX_DEVICES] = {false};
+    hmmc_allow_lds((const void*)gattn_fwd_kernel, 160 * 1024 - 4096, gdone);
+    hipLaunchKernelGGL(gattn_fwd_kernel, dim3(b * H), dim3(256), gl, stream, qkv, out, probs, F, H, causal);
+    return hmmc_launch_status();
+  }
   size_t lds = (size_t)(3 * F * 65 + F * F) * sizeof(float);
   static bool done[HMMC_MAX_DEVICES] = {false};
   hmmc_allow_lds((const void*)tattn_fwd_kernel, 160 * 1024 - 4096, done);
@@ -430,7 +542,15 @@ extern "C" int hmmc_temporal_attention_fwd(const float* qkv, float* out, float* 
 
 extern "C" int hmmc_temporal_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int b,
                                            int F, int H, hipStream_t stream) {
-  if (!qkv || !probs || !dout || !dqkv || b <= 0 || F <= 0 || F > 64 || H <= 0) return HMMC_ERR_ARG;
+  if (!qkv || !probs || !dout || !dqkv || b <= 0 || F <= 0 || H <= 0) return HMMC_ERR_ARG;
+  if (F > GA_MAXL) return HMMC_ERR_UNSUPPORTED;
+  if (F > 64) {
+    size_t gl = (size_t)(2 * F * 65 + 4 * GA_MAXL + GA_MAXL) * sizeof(float);
+    static bool gdone[HMMC_MAX_DEVICES] = {false};
+    hmmc_allow_lds((const void*)gattn_bwd_kernel, 160 * 1024 - 4096, gdone);
+    hipLaunchKernelGGL(gattn_bwd_kernel, dim3(b * H), dim3(256), gl, stream, qkv, probs, dout, dqkv, F, H);
+    return hmmc_launch_status();
+  }
   size_t lds = (size_t)(4 * F * 65 + 2 * F * F) * sizeof(float);
   static bool done[HMMC_MAX_DEVICES] = {false};
   hmmc_allow_lds((const void*)tattn_bwd_kernel, 160 * 1024 - 4096, done);

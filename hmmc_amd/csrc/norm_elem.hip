@@ -299,10 +299,38 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   }
 }
 
-// ---- patch extraction (im2col of the stride=patch conv), fp32 NCHW -> fp16 [N*L, 3*p*p] ---------
+// 8 consecutive elements of an fp16 or fp32 row (the towers' as-written fp16 regime / the reference's fp32-upcast regime,
+// modules/module_clip.py:566-577 followed by model.float()).  The fp32 forms keep every value unrounded.
+__device__ __forceinline__ void store8(half_t* dst, const float (&v)[8]) {
+  h8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+  *reinterpret_cast<h8*>(dst) = o;
+}
+__device__ __forceinline__ void store8(float* dst, const float (&v)[8]) {
+  *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f4*>(dst + 4) = f4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void load8(const half_t* src, float (&v)[8]) {
+  const h8 a = *reinterpret_cast<const h8*>(src);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+}
+__device__ __forceinline__ void load8(const float* src, float (&v)[8]) {
+  const f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+template <typename T> struct is_f16 { static constexpr bool value = false; };
+template <> struct is_f16<half_t> { static constexpr bool value = true; };
+// the rounding a value takes when the reference holds it in a tensor of type T
+template <typename T> __device__ __forceinline__ float rnd(float x) { return is_f16<T>::value ? r16(x) : x; }
+
+// ---- patch extraction (im2col of the stride=patch conv), fp32 NCHW -> fp16 / fp32 [N*L, 3*p*p] ---------
 // Row n*L + 0 is a zero row (class-token slot); row n*L + 1 + gy*g + gx is patch (gy, gx),
 // columns ordered (c, ky, kx) like conv1.weight[width, 3, p, p].
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, half_t* __restrict__ out,
+template <typename TO>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, TO* __restrict__ out,
                                                        int nframes, int H, int W, int p, int g) {
   const int L = g * g + 1;
   const int kc = 3 * p * p / 8;                 // 16-byte chunks per output row
@@ -312,22 +340,18 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     long row = idx / kc;
     int l = (int)(row % L);
     long n = row / L;
-    h8 o;
+    float o[8];
     if (l == 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (half_t)0.f;
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
     } else {
       int gy = (l - 1) / g, gx = (l - 1) % g;
       int per_c = p * p / 8;
       int c = ch / per_c, rem = ch % per_c;
       int ky = rem / (p / 8), kx = (rem % (p / 8)) * 8;
-      const float* src = img + (((n * 3 + c) * H + gy * p + ky) * (long)W + gx * p + kx);
-      f4 a = *reinterpret_cast<const f4*>(src);
-      f4 b = *reinterpret_cast<const f4*>(src + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { o[j] = (half_t)a[j]; o[4 + j] = (half_t)b[j]; }
+      load8(img + (((n * 3 + c) * H + gy * p + ky) * (long)W + gx * p + kx), o);
     }
-    *reinterpret_cast<h8*>(out + idx * 8) = o;
+    store8(out + idx * 8, o);
   }
 }
 
@@ -336,8 +360,9 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 // fp32, then the model's image.type(fp16)): a quarter of the input bytes of the fp32 path.
 struct PixNorm { float mean[3], std[3]; };
 // frame_index (optional): output frame n is read from stored frame frame_index[n] (frame sampling, no gathered copy)
+template <typename TO>
 __global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* __restrict__ img, const int* __restrict__ frame_index,
-                                                          half_t* __restrict__ out, int nframes, int H, int W, int p, int g,
+                                                          TO* __restrict__ out, int nframes, int H, int W, int p, int g,
                                                           PixNorm nm) {
   const int L = g * g + 1;
   const int kc = 3 * p * p / 8;
@@ -347,10 +372,10 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* _
     long row = idx / kc;
     int l = (int)(row % L);
     long n = row / L;
-    h8 o;
+    float o[8];
     if (l == 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (half_t)0.f;
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
     } else {
       int gy = (l - 1) / g, gx = (l - 1) % g;
       int per_c = p * p / 8;
@@ -363,15 +388,16 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* _
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         unsigned b = ((j < 4 ? raw.x : raw.y) >> (8 * (j & 3))) & 0xffu;
-        o[j] = (half_t)((((float)b / 255.0f) - m) / sd);
+        o[j] = (((float)b / 255.0f) - m) / sd;
       }
     }
-    *reinterpret_cast<h8*>(out + idx * 8) = o;
+    store8(out + idx * 8, o);
   }
 }
 
 // x[n][l][:] = fp16( x[n][l][:] + (l == 0 ? fp16(cls) : 0) ) then fp16( . + fp16(pos[l]) )   (in place)
-__global__ __launch_bounds__(256) void vit_embed_kernel(half_t* __restrict__ x, const float* __restrict__ cls,
+template <typename T>
+__global__ __launch_bounds__(256) void vit_embed_kernel(T* __restrict__ x, const float* __restrict__ cls,
                                                         const float* __restrict__ pos, long rows, int L, int D) {
   const int dc = D / 8;
   const long total = rows * dc;
@@ -379,23 +405,24 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(half_t* __restrict__ x, 
     int c = (int)(idx % dc);
     long row = idx / dc;
     int l = (int)(row % L);
-    h8 v = *reinterpret_cast<h8*>(x + idx * 8);
+    float v[8];
+    load8(x + idx * 8, v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float t = (float)v[j];
-      if (l == 0) t = r16(cls[c * 8 + j]);              // conv output of the zero row is 0
-      t = r16(t + r16(pos[l * D + c * 8 + j]));
-      v[j] = (half_t)t;
+      float t = v[j];
+      if (l == 0) t = rnd<T>(cls[c * 8 + j]);           // conv output of the zero row is 0
+      v[j] = rnd<T>(t + rnd<T>(pos[l * D + c * 8 + j]));
     }
-    *reinterpret_cast<h8*>(x + idx * 8) = v;
+    store8(x + idx * 8, v);
   }
 }
 
 // x[b][l][:] = fp16( fp16(table[ids[b][l]][:]) + fp16(pos[l][:]) )
 // ids outside [0, vocab) never index the table: the row is written as the position embedding alone and *err is set
 // (the reference's nn.Embedding raises an index error; a device kernel cannot, so the host checks the flag)
+template <typename TO>
 __global__ __launch_bounds__(256) void text_embed_kernel(const long* __restrict__ ids, const float* __restrict__ table,
-                                                         const float* __restrict__ pos, half_t* __restrict__ x,
+                                                         const float* __restrict__ pos, TO* __restrict__ x,
                                                          long rows, int L, int D, long vocab, int* __restrict__ err) {
   const int dc = D / 8;
   const long total = rows * dc;
@@ -411,13 +438,13 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const long* __restrict_
     f4 a = *reinterpret_cast<const f4*>(tr), b = *reinterpret_cast<const f4*>(tr + 4);
     if (!ok) { a = f4{0.f, 0.f, 0.f, 0.f}; b = a; }
     f4 pa = *reinterpret_cast<const f4*>(pr), pb = *reinterpret_cast<const f4*>(pr + 4);
-    h8 o;
+    float o[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      o[j] = (half_t)(r16(a[j]) + r16(pa[j]));
-      o[4 + j] = (half_t)(r16(b[j]) + r16(pb[j]));
+      o[j] = rnd<TO>(a[j]) + rnd<TO>(pa[j]);
+      o[4 + j] = rnd<TO>(b[j]) + rnd<TO>(pb[j]);
     }
-    *reinterpret_cast<h8*>(x + idx * 8) = o;
+    store8(x + idx * 8, o);
   }
 }
 
@@ -427,7 +454,8 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const long* __restrict_
 // the 8 partial sums are added in wave order: a fixed summation tree whatever the launch timing.  Ids that occur once
 // (most of them) cost one pass over the id list; the padding id's thousands of rows are 8 independent load chains.
 constexpr int TE_THREADS = 512, TE_WAVES = 8, TE_LIST = 16384;
-__global__ __launch_bounds__(TE_THREADS) void text_embed_bwd_kernel(const long* __restrict__ ids, const half_t* __restrict__ dx,
+template <typename TI>
+__global__ __launch_bounds__(TE_THREADS) void text_embed_bwd_kernel(const long* __restrict__ ids, const TI* __restrict__ dx,
                                                                     float* __restrict__ dtable, int rows, int D, long vocab) {
   __shared__ unsigned short list[TE_LIST];
   __shared__ int wave_cnt[TE_WAVES];
@@ -469,9 +497,10 @@ __global__ __launch_bounds__(TE_THREADS) void text_embed_bwd_kernel(const long* 
       const int col = c0 + lane * 8;
       if (col < D) {
         for (int i = wid; i < n; i += TE_WAVES) {
-          const h8 v = *reinterpret_cast<const h8*>(dx + (size_t)(start + list[i]) * D + col);
+          float v[8];
+          load8(dx + (size_t)(start + list[i]) * D + col, v);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+          for (int j = 0; j < 8; ++j) acc[j] += v[j];
         }
       }
       __syncthreads();
@@ -675,50 +704,70 @@ extern "C" int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int 
   return hmmc_launch_status();
 }
 
-extern "C" int hmmc_patchify(const float* img, void* out, int nframes, int H, int W, int patch, hipStream_t stream) {
+extern "C" int hmmc_patchify(const float* img, void* out, int nframes, int H, int W, int patch, int out_dtype, hipStream_t stream) {
   if (!img || !out || nframes <= 0) return HMMC_ERR_ARG;
   if (patch % 8 || H % patch || W % patch || H != W || (W & 3)) return HMMC_ERR_UNSUPPORTED;
   int g = H / patch;
   long total = (long)nframes * (g * g + 1) * (3 * patch * patch / 8);
-  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, img, (half_t*)out, nframes, H, W,
-                     patch, g);
+  if (out_dtype == 0)
+    hipLaunchKernelGGL(patchify_kernel<half_t>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, img, (half_t*)out, nframes, H,
+                       W, patch, g);
+  else
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, img, (float*)out, nframes, H, W,
+                       patch, g);
   return hmmc_launch_status();
 }
 
 extern "C" int hmmc_patchify_u8(const void* img, const int* frame_index, void* out, int nframes, int H, int W, int patch,
-                                const float* mean3, const float* std3, hipStream_t stream) {
+                                const float* mean3, const float* std3, int out_dtype, hipStream_t stream) {
   if (!img || !out || !mean3 || !std3 || nframes <= 0) return HMMC_ERR_ARG;      // mean3 / std3: HOST arrays of 3 floats
   if (patch % 8 || H % patch || W % patch || H != W || (W & 7) || ((uintptr_t)img & 7)) return HMMC_ERR_UNSUPPORTED;
   int g = H / patch;
   PixNorm nm;
   for (int c = 0; c < 3; ++c) { nm.mean[c] = mean3[c]; nm.std[c] = std3[c]; }
   long total = (long)nframes * (g * g + 1) * (3 * patch * patch / 8);
-  hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, (const unsigned char*)img, frame_index,
-                     (half_t*)out, nframes, H, W, patch, g, nm);
+  if (out_dtype == 0)
+    hipLaunchKernelGGL(patchify_u8_kernel<half_t>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, (const unsigned char*)img,
+                       frame_index, (half_t*)out, nframes, H, W, patch, g, nm);
+  else
+    hipLaunchKernelGGL(patchify_u8_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, (const unsigned char*)img,
+                       frame_index, (float*)out, nframes, H, W, patch, g, nm);
   return hmmc_launch_status();
 }
 
-extern "C" int hmmc_vit_embed(void* x, const float* cls, const float* pos, long rows, int L, int D, hipStream_t stream) {
+extern "C" int hmmc_vit_embed(void* x, const float* cls, const float* pos, long rows, int L, int D, int dtype, hipStream_t stream) {
   if (!x || !cls || !pos || rows <= 0 || D % 8) return HMMC_ERR_ARG;
-  hipLaunchKernelGGL(vit_embed_kernel, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, (half_t*)x, cls, pos,
-                     rows, L, D);
+  if (dtype == 0)
+    hipLaunchKernelGGL(vit_embed_kernel<half_t>, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, (half_t*)x, cls,
+                       pos, rows, L, D);
+  else
+    hipLaunchKernelGGL(vit_embed_kernel<float>, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, (float*)x, cls, pos,
+                       rows, L, D);
   return hmmc_launch_status();
 }
 
 extern "C" int hmmc_text_embed(const long* ids, const float* table, const float* pos, void* x, long rows, int L, int D,
-                               long vocab, int* err_flag, hipStream_t stream) {
+                               long vocab, int* err_flag, int out_dtype, hipStream_t stream) {
   if (!ids || !table || !pos || !x || rows <= 0 || D % 8 || vocab <= 0) return HMMC_ERR_ARG;
-  hipLaunchKernelGGL(text_embed_kernel, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, ids, table, pos,
-                     (half_t*)x, rows, L, D, vocab, err_flag);
+  if (out_dtype == 0)
+    hipLaunchKernelGGL(text_embed_kernel<half_t>, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, ids, table, pos,
+                       (half_t*)x, rows, L, D, vocab, err_flag);
+  else
+    hipLaunchKernelGGL(text_embed_kernel<float>, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, ids, table, pos,
+                       (float*)x, rows, L, D, vocab, err_flag);
   return hmmc_launch_status();
 }
 
-extern "C" int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, long vocab,
+extern "C" int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, long vocab, int dx_dtype,
                                    hipStream_t stream) {
   if (!ids || !dx || !dtable || rows <= 0 || vocab <= 0) return HMMC_ERR_ARG;
   if (D % 8 || rows > 0x7fffffffL) return HMMC_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(text_embed_bwd_kernel, dim3((unsigned)rows), dim3(TE_THREADS), 0, stream, ids, (const half_t*)dx, dtable,
-                     (int)rows, D, vocab);
+  if (dx_dtype == 0)
+    hipLaunchKernelGGL(text_embed_bwd_kernel<half_t>, dim3((unsigned)rows), dim3(TE_THREADS), 0, stream, ids, (const half_t*)dx,
+                       dtable, (int)rows, D, vocab);
+  else
+    hipLaunchKernelGGL(text_embed_bwd_kernel<float>, dim3((unsigned)rows), dim3(TE_THREADS), 0, stream, ids, (const float*)dx, dtable,
+                       (int)rows, D, vocab);
   return hmmc_launch_status();
 }
 

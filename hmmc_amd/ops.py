@@ -173,14 +173,23 @@ def colsum(x2d, out_dtype=None, round_f16=False):
     return out
 
 
-def patchify(video4d, patch):
-    """fp32 [n,3,H,W] -> fp16 [n*(g*g+1), 3*p*p] with a zero row in every frame's class-token slot."""
+def _dt(dtype):
+    """dtype code of the C-ABI: 0 fp16 (the towers as written), 1 fp32 (the reference after model.float())."""
+    if dtype == torch.float16:
+        return 0
+    if dtype == torch.float32:
+        return 1
+    raise TypeError(f"the CLIP towers run in fp16 (as written) or fp32 (model.float()), not {dtype}")
+
+
+def patchify(video4d, patch, dtype=torch.float16):
+    """fp32 [n,3,H,W] -> `dtype` [n*(g*g+1), 3*p*p] with a zero row in every frame's class-token slot."""
     _chk(video4d, torch.float32, "video")
     n, c, H, W = video4d.shape
     assert c == 3
     g = H // patch
-    out = torch.empty((n * (g * g + 1), 3 * patch * patch), dtype=torch.float16, device=video4d.device)
-    call("hmmc_patchify", ptr(video4d), ptr(out), n, H, W, patch)
+    out = torch.empty((n * (g * g + 1), 3 * patch * patch), dtype=dtype, device=video4d.device)
+    call("hmmc_patchify", ptr(video4d), ptr(out), n, H, W, patch, _dt(dtype))
     return out
 
 
@@ -188,7 +197,7 @@ CLIP_PIXEL_MEAN = (0.48145466, 0.4578275, 0.40821073)      # dataloaders/rawvide
 CLIP_PIXEL_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def patchify_u8(video4d_u8, patch, mean=CLIP_PIXEL_MEAN, std=CLIP_PIXEL_STD, frame_index=None):
+def patchify_u8(video4d_u8, patch, mean=CLIP_PIXEL_MEAN, std=CLIP_PIXEL_STD, frame_index=None, dtype=torch.float16):
     """uint8 [n,3,H,W] -> fp16 patches as patchify(), with x/255 and the per-channel normalisation fused in.
     frame_index (int32 [m] on the device): patches of the m frames video4d_u8[frame_index[i]] instead (frame sampling)."""
     import ctypes
@@ -199,36 +208,37 @@ def patchify_u8(video4d_u8, patch, mean=CLIP_PIXEL_MEAN, std=CLIP_PIXEL_STD, fra
         _chk(frame_index, torch.int32, "frame_index")
         n = frame_index.numel()
     g = H // patch
-    out = torch.empty((n * (g * g + 1), 3 * patch * patch), dtype=torch.float16, device=video4d_u8.device)
+    out = torch.empty((n * (g * g + 1), 3 * patch * patch), dtype=dtype, device=video4d_u8.device)
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
-    call("hmmc_patchify_u8", ptr(video4d_u8), ptr(frame_index), ptr(out), n, H, W, patch, m3, s3)
+    call("hmmc_patchify_u8", ptr(video4d_u8), ptr(frame_index), ptr(out), n, H, W, patch, m3, s3, _dt(dtype))
     return out
 
 
 def vit_embed_(x, cls, pos, L):
-    _chk(x, torch.float16, "x")
+    _chk(x, x.dtype, "x")
     _chk(cls, torch.float32, "cls")
     _chk(pos, torch.float32, "pos")
-    call("hmmc_vit_embed", ptr(x), ptr(cls), ptr(pos), x.shape[0], L, x.shape[1])
+    call("hmmc_vit_embed", ptr(x), ptr(cls), ptr(pos), x.shape[0], L, x.shape[1], _dt(x.dtype))
     return x
 
 
-def text_embed(ids, table, pos):
+def text_embed(ids, table, pos, dtype=torch.float16):
     _chk(ids, torch.int64, "ids")
     _chk(table, torch.float32, "table")
     _chk(pos, torch.float32, "pos")
     b, L = ids.shape
     D = table.shape[1]
-    x = torch.empty((b * L, D), dtype=torch.float16, device=ids.device)
-    call("hmmc_text_embed", ptr(ids), ptr(table), ptr(pos), ptr(x), b * L, L, D, table.shape[0], ptr(device_error_flag(ids.device)))
+    x = torch.empty((b * L, D), dtype=dtype, device=ids.device)
+    call("hmmc_text_embed", ptr(ids), ptr(table), ptr(pos), ptr(x), b * L, L, D, table.shape[0], ptr(device_error_flag(ids.device)),
+         _dt(dtype))
     return x
 
 
 def text_embed_bwd(ids, dx, vocab):
-    _chk(dx, torch.float16, "dx")
+    _chk(dx, dx.dtype, "dx")
     D = dx.shape[-1]
     dtable = torch.zeros((vocab, D), dtype=torch.float32, device=dx.device)
-    call("hmmc_text_embed_bwd", ptr(ids), ptr(dx), ptr(dtable), ids.numel(), D, vocab)
+    call("hmmc_text_embed_bwd", ptr(ids), ptr(dx), ptr(dtable), ids.numel(), D, vocab, _dt(dx.dtype))
     return dtable
 
 

@@ -102,25 +102,28 @@ int hmmc_colsum(const void* X, void* out, int M, int N, long ld, int in_dtype, i
                 void* workspace, size_t ws_bytes, hmmc_stream_t stream);
 
 /* Patch extraction for conv1 (kernel = stride = patch, modules/module_clip.py:278,307-310):
- * fp32 NCHW frames -> fp16 [nframes*(g*g+1), 3*patch*patch]; row 0 of each frame is zero (class slot). */
-int hmmc_patchify(const float* img, void* out, int nframes, int H, int W, int patch, hmmc_stream_t stream);
+ * fp32 NCHW frames -> [nframes*(g*g+1), 3*patch*patch]; row 0 of each frame is zero (class slot).
+ * out_dtype / dtype of the entry points below: 0 = fp16 (the towers as written, convert_weights, module_clip.py:506-527,
+ * image.type(fp16) at module_cross.py:224), 1 = fp32 (the reference after model.float(): no value is rounded). */
+int hmmc_patchify(const float* img, void* out, int nframes, int H, int W, int patch, int out_dtype, hmmc_stream_t stream);
 /* The same from uint8 NCHW frames with the loader's normalisation fused in (dataloaders/dataloader_msrvtt_retrieval.py:
  * 242-247: x/255, (x - mean[c]) / std[c] in fp32, then fp16): a quarter of the input bytes.  mean3 / std3 are HOST arrays.
  * frame_index (device int32 [nframes], may be NULL): output frame n is read from stored frame frame_index[n] of img - the
  * loader's frame sampling (:296-312 sample_slice) applied in place, without a gathered copy of the chosen frames. */
 int hmmc_patchify_u8(const void* img, const int* frame_index, void* out, int nframes, int H, int W, int patch,
-                     const float* mean3, const float* std3, hmmc_stream_t stream);
+                     const float* mean3, const float* std3, int out_dtype, hmmc_stream_t stream);
 /* In place on the patch-GEMM output: class_embedding into row 0, + positional_embedding
- * (modules/module_clip.py:311-312), with the reference's fp16 rounding points. */
-int hmmc_vit_embed(void* x, const float* cls, const float* pos, long rows, int L, int D, hmmc_stream_t stream);
+ * (modules/module_clip.py:311-312), with the reference's fp16 rounding points (dtype 0) or in fp32 (dtype 1). */
+int hmmc_vit_embed(void* x, const float* cls, const float* pos, long rows, int L, int D, int dtype, hmmc_stream_t stream);
 /* token_embedding(ids).half() + positional_embedding[:L].half() (modules/module_cross.py:288-291).  An id outside
  * [0, vocab) never indexes the table (the reference's nn.Embedding raises): its row is the position embedding alone and
  * *err_flag (device int, may be NULL) is set to 1 for the host to check. */
 int hmmc_text_embed(const long* ids, const float* table, const float* pos, void* x, long rows, int L, int D, long vocab,
-                    int* err_flag, hmmc_stream_t stream);
+                    int* err_flag, int out_dtype, hmmc_stream_t stream);
 /* dense fp32 embedding gradient: dtable[id] = sum of dx[r] over the rows with ids[r] == id (dtable zeroed by the caller;
- * ids outside [0, vocab) contribute nothing).  No atomics: bit-identical from run to run.  rows < 65536. */
-int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, long vocab, hmmc_stream_t stream);
+ * ids outside [0, vocab) contribute nothing).  No atomics: bit-identical from run to run.  dx_dtype: 0 fp16, 1 fp32. */
+int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, long vocab, int dx_dtype,
+                        hmmc_stream_t stream);
 /* kind 0: fp16 -> fp32, 1: fp32 -> fp16 */
 int hmmc_cast(const void* in, void* out, long n, int kind, hmmc_stream_t stream);
 
@@ -190,7 +193,9 @@ int hmmc_temporal_pool_bwd(const float* h, const float* u, const float* norms, c
                            int D, hmmc_stream_t stream);
 /* out[r] = x[r] + table[r % period]  (frame_position_embeddings, modules/module_cross.py:195-199). */
 int hmmc_add_rowbias(const float* x, const float* table, float* out, long rows, int period, int D, hmmc_stream_t stream);
-/* fp32 attention of the temporal blocks, sequence length F <= 64, head dim 64 (modules/module_cross.py:127-131). */
+/* fp32 attention, head dim 64, probabilities saved [b, H, F, F]: the temporal blocks (modules/module_cross.py:127-131; F <= 64:
+ * one wave per (video, head)) and, for 65 <= F <= 256, the CLIP towers in the reference's fp32-upcast regime (model.float():
+ * ViT-B/16's 197 tokens, a 77-token text; a parity path: one workgroup per (sequence, head), exact fp32, not tuned). */
 int hmmc_temporal_attention_fwd(const float* qkv, float* out, float* probs, int b, int F, int H, int causal,
                                 hmmc_stream_t stream);
 int hmmc_temporal_attention_bwd(const float* qkv, const float* probs, const float* dout, float* dqkv, int b, int F, int H,
