@@ -40,21 +40,39 @@ def _dgrad16(dy, w, aux_in=None, epilogue=0):
     return ops.gemm_f16(dy, w, T, w.shape[1], Np, a_kmajor=True, b_kmajor=False, aux_in=aux_in, epilogue=epilogue)
 
 
+# The CLIP towers run in the dtype of their weights: fp16 as the reference builds them (convert_weights), or fp32 after
+# model.float() (the reference's fp32-upcast regime, modules/module_clip.py:566-577 + .float()): the same stages on the
+# exact-f32 MFMA GEMM, fp32 LayerNorm / attention / embeddings, nothing rounded to fp16.  A parity regime: correct, not tuned.
+def _linear(x, w):
+    """x[M,K] w[N,K]^T in the operands' dtype."""
+    if x.dtype != w.dtype:
+        raise RuntimeError(f"expected the activations ({x.dtype}) and the weights ({w.dtype}) to have the same dtype: after "
+                           "model.float() set text_encoder.dtype = torch.float32 as well, as with the reference")
+    if w.dtype == torch.float16:
+        return ops.gemm_f16(x, w, x.shape[0], w.shape[0], x.shape[1])
+    return ops.linear_f32(x, w)
+
+
+def _wgrad(dy, x):
+    return _wgrad16(dy, x) if dy.dtype == torch.float16 else ops.wgrad_f32(dy, x)
+
+
 class VitEmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, video4d, conv_w, cls, pos, ln_w, ln_b, frame_index=None):
         n = video4d.shape[0] if frame_index is None else frame_index.numel()
         D, _, p, _ = conv_w.shape
         L = pos.shape[0]
-        # [n*L, 3pp] fp16, class rows zero; uint8 frames are normalised on the fly (CLIP mean / std) and, with a frame
-        # index, picked out of the stored frames in place (the loader's frame sampling)
+        # [n*L, 3pp] in the conv weight's dtype (image.type(self.dtype), modules/module_cross.py:224), class rows zero; uint8
+        # frames are normalised on the fly (CLIP mean / std) and, with a frame index, picked out of the stored frames in place
+        # (the loader's frame sampling)
         if video4d.dtype == torch.uint8:
-            patches = ops.patchify_u8(video4d, p, frame_index=frame_index)
+            patches = ops.patchify_u8(video4d, p, frame_index=frame_index, dtype=conv_w.dtype)
         else:
             if frame_index is not None:
                 raise TypeError("frame sampling on the device takes the stored uint8 frames")
-            patches = ops.patchify(video4d, p)
-        x0 = ops.gemm_f16(patches, conv_w.view(D, -1), n * L, D, 3 * p * p)
+            patches = ops.patchify(video4d, p, dtype=conv_w.dtype)
+        x0 = _linear(patches, conv_w.view(D, -1))
         ops.vit_embed_(x0, cls, pos, L)
         x, mean, rstd = ops.layernorm_fwd(x0, ln_w, ln_b, 1e-5)
         ctx.save_for_backward(patches, x0, mean, rstd, ln_w, conv_w)
@@ -66,17 +84,17 @@ class VitEmbedFn(torch.autograd.Function):
         patches, x0, mean, rstd, ln_w, conv_w = ctx.saved_tensors
         n, L, D, p = ctx.dims
         dx0, dlw, dlb = ops.layernorm_bwd(dx.contiguous(), x0, ln_w, mean, rstd)
-        dconv = _wgrad16(dx0, patches).view(conv_w.shape)
-        dpos = ops.colsum(dx0.view(n, L * D), out_dtype=torch.float32, round_f16=True).view(L, D)
+        dconv = _wgrad(dx0, patches).view(conv_w.shape)
+        dpos = ops.colsum(dx0.view(n, L * D), out_dtype=torch.float32, round_f16=dx0.dtype == torch.float16).view(L, D)
         return None, dconv, dpos[0].clone(), dpos, dlw, dlb, None
 
 
 class TextEmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, table, pos):
+    def forward(ctx, ids, table, pos, dtype=torch.float16):
         ctx.save_for_backward(ids)
         ctx.dims = (table.shape[0], pos.shape[0])
-        return ops.text_embed(ids.contiguous(), table, pos)
+        return ops.text_embed(ids.contiguous(), table, pos, dtype=dtype)
 
     @staticmethod
     def backward(ctx, dx):
@@ -87,8 +105,8 @@ class TextEmbedFn(torch.autograd.Function):
         D = dx.shape[-1]
         dtable = ops.text_embed_bwd(ids, dx, vocab)
         dpos = torch.zeros((ctx_len, D), dtype=torch.float32, device=dx.device)
-        dpos[:L] = ops.colsum(dx.view(b, L * D), out_dtype=torch.float32, round_f16=True).view(L, D)
-        return None, dtable, dpos
+        dpos[:L] = ops.colsum(dx.view(b, L * D), out_dtype=torch.float32, round_f16=dx.dtype == torch.float16).view(L, D)
+        return None, dtable, dpos, None
 
 
 def _ptr_array(tensors):
@@ -142,15 +160,20 @@ class ClipTransformerFn(torch.autograd.Function):
         for prm in params:
             if not prm.is_contiguous():
                 raise ValueError("tower parameters must be contiguous")
-        y, acts = _tower_forward(x, params, nseq, L, heads, causal, 1e-5, False, keep, lead_only)
+        fp32 = x.dtype == torch.float32
+        if any(prm.dtype != (x.dtype if prm.dim() == 2 else prm.dtype) for prm in params):
+            raise RuntimeError(f"expected the activations ({x.dtype}) and the tower weights to have the same dtype: after "
+                               "model.float() set text_encoder.dtype = torch.float32 as well, as with the reference")
+        lead_only = bool(lead_only and not fp32)        # the class-token pruning exists for the fp16 tower only
+        y, acts = _tower_forward(x, params, nseq, L, heads, causal, 1e-5, fp32, keep, lead_only)
         ctx.acts, ctx.x0, ctx.params = acts, (x if keep else None), params
-        ctx.cfg = (nseq, L, heads, causal, lead_only)
+        ctx.cfg = (nseq, L, heads, causal, lead_only, fp32)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        nseq, L, heads, causal, lead_only = ctx.cfg
-        dx, grads = _tower_backward(dy.contiguous(), ctx.x0, ctx.params, ctx.acts, nseq, L, heads, causal, False, lead_only)
+        nseq, L, heads, causal, lead_only, fp32 = ctx.cfg
+        dx, grads = _tower_backward(dy.contiguous(), ctx.x0, ctx.params, ctx.acts, nseq, L, heads, causal, fp32, lead_only)
         ctx.acts = ctx.x0 = None
         return (dx, None, None, None, None, None, *grads)
 
@@ -163,18 +186,26 @@ class LnProjFn(torch.autograd.Function):
         D, E = proj.shape
         y, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, 1e-5, row_index=row_index)
         R = y.shape[0]
-        f16 = ops.gemm_f16(y, proj, R, E, D, a_kmajor=True, b_kmajor=False)
+        if y.dtype != proj.dtype:
+            raise RuntimeError(f"expected the activations ({y.dtype}) and the projection ({proj.dtype}) to have the same dtype")
         ctx.save_for_backward(x, row_index, ln_w, proj, y, mean, rstd)
-        return f16.float()
+        if proj.dtype == torch.float32:
+            return ops.dgrad_f32(y, proj)                 # y @ proj, fp32 regime
+        return ops.gemm_f16(y, proj, R, E, D, a_kmajor=True, b_kmajor=False).float()
 
     @staticmethod
     def backward(ctx, dout):
         x, row_index, ln_w, proj, y, mean, rstd = ctx.saved_tensors
         D, E = proj.shape
         R = y.shape[0]
-        d16 = dout.contiguous().half()
-        dy = ops.gemm_f16(d16, proj, R, D, E, a_kmajor=True, b_kmajor=True)          # dy = d16 @ proj^T
-        dproj = ops.gemm_f16(y, d16, D, E, R, a_kmajor=False, b_kmajor=False)        # y^T d16
+        if proj.dtype == torch.float32:
+            d32 = dout.contiguous()
+            dy = ops.linear_f32(d32, proj)                                           # d @ proj^T
+            dproj = ops.wgrad_f32(y, d32)                                            # y^T d
+        else:
+            d16 = dout.contiguous().half()
+            dy = ops.gemm_f16(d16, proj, R, D, E, a_kmajor=True, b_kmajor=True)      # dy = d16 @ proj^T
+            dproj = ops.gemm_f16(y, d16, D, E, R, a_kmajor=False, b_kmajor=False)    # y^T d16
         if row_index is not None:
             dx = torch.zeros_like(x)
             dx, dlw, dlb = ops.layernorm_bwd(dy, x, ln_w, mean, rstd, row_index=row_index, dx=dx)

@@ -71,9 +71,8 @@ class Transformer(nn.Module):
     def forward(self, x, nseq, L, lead_only=False):
         """x: [nseq*L, width] fp16 -> same shape.  lead_only: the caller reads only token 0 of every sequence of the result
         (the class token), so the last block's per-token half runs on those rows alone; the other rows are undefined."""
-        if x.dtype != torch.float16:
-            raise NotImplementedError("the HIP CLIP towers run the reference's as-written fp16 regime; "
-                                      "model.float() (fp32-upcast) is not supported on this path")
+        if x.dtype not in (torch.float16, torch.float32):
+            raise TypeError(f"the CLIP towers run in fp16 (as written) or fp32 (after model.float()), not {x.dtype}")
         # One native call per direction on a single GPU.  Under data parallelism the tower is cut into runs of
         # `ddp_layers_per_node` layers, one autograd node each, so that the gradients of the upper layers reach DDP's
         # bucket hooks (and the xGMI all-reduce starts) while the lower layers are still in their backward pass.

@@ -179,7 +179,9 @@ class TextEncoder(nn.Module):
         b, L = text.shape
         if L > self.positional_embedding.shape[0]:
             raise ValueError("sequence longer than the positional embedding table")
-        x = Fn.TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding)
+        # activations in self.dtype, a STORED attribute as in the reference (module_cross.py:256,288): model.float() alone leaves
+        # it at fp16 and the text path then fails on mixed dtypes; the fp32 regime sets text_encoder.dtype = torch.float32 too
+        x = Fn.TextEmbedFn.apply(text, self.token_embedding.weight, self.positional_embedding, self.dtype)
         x = self.transformer(x, b, L)
         feat = hidden = None
         if _want in ("both", "hidden"):
