@@ -30,6 +30,10 @@
                      // 3 / 4 / 5: s_memrealtime stamps of the third work item into p.ws (scratch/gemm_stamps.py), 4 = 1 + stamps, 5 = 2 + stamps
 #endif
 
+#ifndef HMMC_PF
+#define HMMC_PF 6     // prefetch distance of the 256x256 K-loop in half-tiles (scratch experiments build 4)
+#endif
+
 namespace {
 
 constexpr int BKT = 64;
@@ -532,10 +536,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
       acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[ks][j], af[ks][i], acc[I0 + i][J0 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0); } while (0)
+#if HMMC_PF == 6
+#define HMMC_VMW "s_waitcnt vmcnt(8)"
+#define HMMC_ST1() stage_b(1)
+#define HMMC_ST2() do { stage_a(1); s_advance(); } while (0)
+#define HMMC_ST3() stage_a(0)
+#define HMMC_ST4() stage_b(0)
     stage_a(0); stage_b(0); stage_b(1); stage_a(1);
     s_advance();
     stage_a(0); stage_b(0);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else      // distance 4: two half-tiles in flight at every wait (sensitivity experiment)
+#define HMMC_VMW "s_waitcnt vmcnt(4)"
+#define HMMC_ST1() stage_a(0)
+#define HMMC_ST2() stage_b(0)
+#define HMMC_ST3() stage_b(1)
+#define HMMC_ST4() do { stage_a(1); s_advance(); } while (0)
+    stage_a(0); stage_b(0); stage_b(1); stage_a(1);
+    s_advance();
+#endif
+    asm volatile(HMMC_VMW ::: "memory");
     HMMC_BAR();
     if (wm == 1) HMMC_BAR();
     const int arow = wm * 64, brow = wn * 32;
@@ -551,8 +570,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<AK, 128>(base, arow + i * 16, ks, lane);
-      stage_b(1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      HMMC_ST1();
+      asm volatile(HMMC_VMW ::: "memory");
       HMMC_BAR();
       HMMC_MM(0, 0, b0f);
       HMMC_BAR();
@@ -562,9 +581,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) b1f[ks][j] = read_frag<BK, 128>(base + 3 * HALF, brow + j * 16, ks, lane);
-      stage_a(1);
-      s_advance();
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      HMMC_ST2();
+      asm volatile(HMMC_VMW ::: "memory");
       HMMC_BAR();
       HMMC_MM(0, 2, b1f);
       HMMC_BAR();
@@ -574,15 +592,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<AK, 128>(base + HALF, arow + i * 16, ks, lane);
-      stage_a(0);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      HMMC_ST3();
+      asm volatile(HMMC_VMW ::: "memory");
       HMMC_BAR();
       HMMC_MM(4, 2, b1f);
       HMMC_BAR();
       HMMC_STAMP();
       // phase 4
-      stage_b(0);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      HMMC_ST4();
+      asm volatile(HMMC_VMW ::: "memory");
       HMMC_BAR();
       HMMC_MM(4, 0, b0f);
       HMMC_BAR();
