@@ -15,9 +15,33 @@ namespace {
 // per head instead of four times and has no global load between the first MFMA and the last.
 constexpr float LOG2E = 1.4426950408889634f;
 
-template <int KTL, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_long_fwd_kernel(AttnArgs p) {
-  constexpr int ROWS = 16 * KTL;
+// LDS images of the head's operands: [rows][64 halves] = 128-byte rows WITHOUT padding (57 KiB for K and V of 224 rows, so two
+// workgroups fit a CU), the 16-byte chunk index XORed with a key of the row so that both access patterns are conflict-free:
+//   "row" image (read with ds_read_b128: 16 lanes on 16 consecutive rows, one chunk each): key = (row >> 1) & 7
+//   "tr" image (read with ds_read_b64_tr_b16: 8 consecutive rows x 32 contiguous bytes per 32 lanes): key = ((row >> 1) & 3) << 1
+__device__ __forceinline__ int swz_row(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int swz_tr(int row) { return ((row >> 1) & 3) << 1; }
+// 8 halves op[row][8 chunk .. +7] of a "row" image
+__device__ __forceinline__ h8 row_frag(const half_t* tile, int row, int chunk) {
+  return *reinterpret_cast<const h8*>(tile + row * DH + ((chunk ^ swz_row(row)) << 3));
+}
+// transposed fragment of a "tr" image: T[k][c0 + (lane & 15)], k = rows rA + 4g + j (j < 4) and rB + 4g + j - 4
+__device__ __forceinline__ h8 tr_frag_swz(const half_t* tile, int rA, int rB, int c0, int lane) {
+  const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+  const int ra = rA + 4 * g + qq, rb = rB + 4 * g + qq;
+  const int chunk = (c0 >> 3) + (pp >> 1), sub = 4 * (pp & 1);
+  h4 lo = tr_read(tile + ra * DH + ((chunk ^ swz_tr(ra)) << 3) + sub);
+  h4 hi = tr_read(tile + rb * DH + ((chunk ^ swz_tr(rb)) << 3) + sub);
+  return cat4(lo, hi);
+}
+
+constexpr int fwd_lds_bytes(int KTL, int NW) { return 2 * 16 * KTL * DH * 2 + NW * 16 * LDS_STRIDE * 2; }   // K, V images + a staging tile per wave
+// waves per SIMD the register allocation must leave room for: the workgroups the LDS lets a CU hold x NW / 4
+constexpr int fwd_min_waves(int KTL, int NW) { return (160 * 1024 / fwd_lds_bytes(KTL, NW) >= 2 ? 2 : 1) * NW / 4; }
+
+template <int KTL, int NW, bool CAUSAL>
+__global__ __launch_bounds__(64 * NW, fwd_min_waves(KTL, NW)) void attn_long_fwd_kernel(AttnArgs p) {
+  constexpr int ROWS = 16 * KTL, NT = 64 * NW, RPP = NT / 8, PASSES = (ROWS + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -28,24 +52,26 @@ __global__ __launch_bounds__(256, 2) void attn_long_fwd_kernel(AttnArgs p) {
   const half_t* k = q + D;
   const half_t* v = q + 2 * D;
   half_t* ktile = reinterpret_cast<half_t*>(smem);
-  half_t* vtile = ktile + ROWS * LDS_STRIDE;
-  half_t* scr = vtile + ROWS * LDS_STRIDE + wid * (16 * LDS_STRIDE);
+  half_t* vtile = ktile + ROWS * DH;
+  half_t* scr = vtile + ROWS * DH + wid * (16 * LDS_STRIDE);
   const int g = lane >> 4, c = lane & 15;
-  {                                              // K, V -> LDS: thread -> row (tid >> 3) + 32 i, bytes 16 (tid & 7) .. +15; rows past L zero
-    u4v rk[ROWS / 32], rv[ROWS / 32];
+  {                                              // K, V -> LDS: thread -> row (tid >> 3) + RPP i, chunk tid & 7; rows past L zero
+    u4v rk[PASSES], rv[PASSES];
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      const int row = (tid >> 3) + 32 * i;
+    for (int i = 0; i < PASSES; ++i) {
+      const int row = (tid >> 3) + RPP * i;
       const long off = (long)min(row, L - 1) * ld + 8 * (tid & 7);
       rk[i] = *reinterpret_cast<const u4v*>(k + off);
       rv[i] = *reinterpret_cast<const u4v*>(v + off);
     }
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      const int row = (tid >> 3) + 32 * i;
+    for (int i = 0; i < PASSES; ++i) {
+      const int row = (tid >> 3) + RPP * i, ch = tid & 7;
       const u4v z = {0u, 0u, 0u, 0u};
-      *reinterpret_cast<u4v*>(ktile + row * LDS_STRIDE + 8 * (tid & 7)) = row < L ? rk[i] : z;
-      *reinterpret_cast<u4v*>(vtile + row * LDS_STRIDE + 8 * (tid & 7)) = row < L ? rv[i] : z;
+      if (ROWS % RPP == 0 || row < ROWS) {
+        *reinterpret_cast<u4v*>(ktile + row * DH + ((ch ^ swz_row(row)) << 3)) = row < L ? rk[i] : z;
+        *reinterpret_cast<u4v*>(vtile + row * DH + ((ch ^ swz_tr(row)) << 3)) = row < L ? rv[i] : z;
+      }
     }
   }
   __syncthreads();
@@ -57,78 +83,77 @@ __global__ __launch_bounds__(256, 2) void attn_long_fwd_kernel(AttnArgs p) {
     for (int t = 0; t < 2; ++t)
       raw[t] = *reinterpret_cast<const u4v*>(q + (long)min(qt * 16 + (lane >> 3) + 8 * t, L - 1) * ld + 8 * (lane & 7));
   };
+  constexpr float C1 = 0.125f * LOG2E;
   u4v qraw[2], qnext[2];
   load_q(min(wid, nqt - 1), qraw);
-  for (int qt = wid; qt < nqt; qt += 4) {
+  for (int qt = wid; qt < nqt; qt += NW) {
     const int q0 = qt * 16, qi = q0 + c;
-    load_q(min(qt + 4, nqt - 1), qnext);
+    load_q(min(qt + NW, nqt - 1), qnext);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       *reinterpret_cast<u4v*>(scr + ((lane >> 3) + 8 * t) * LDS_STRIDE + 8 * (lane & 7)) = qraw[t];
     h8 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const h8*>(scr + c * LDS_STRIDE + ks * 32 + 8 * g);
-    // S^T[key][q]: lane holds keys kt*16 + 4g + r of query column qi, for every key tile
+    // S^T[key][q]: lane holds keys kt*16 + 4g + r of query column qi, for every key tile; two key tiles per round
     f4 s[KTL];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {         // the K fragments of half the key tiles are requested together, then multiplied
-      h8 kf[KTL / 2][2];
-#pragma unroll
-      for (int i = 0; i < KTL / 2; ++i) {
-        const half_t* kr = ktile + ((half * (KTL / 2) + i) * 16 + c) * LDS_STRIDE + 8 * g;
-        kf[i][0] = *reinterpret_cast<const h8*>(kr);
-        kf[i][1] = *reinterpret_cast<const h8*>(kr + 32);
-      }
-#pragma unroll
-      for (int i = 0; i < KTL / 2; ++i) {
-        f4 z = {0.f, 0.f, 0.f, 0.f};
-        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][0], qf[0], z, 0, 0, 0);
-        s[half * (KTL / 2) + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][1], qf[1], z, 0, 0, 0);
-      }
-    }
     float m = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < KTL; ++kt)
+    for (int k0 = 0; k0 < KTL; k0 += 2) {
+      h8 kf[2][2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        float val = s[kt][r] * (0.125f * LOG2E);                  // base-2 exponent: exp(x) = exp2(x log2 e)
-        // keys past L can only sit in the last two tiles (KTL = key tiles rounded up to an even count): no test elsewhere
-        if (CAUSAL) val = (key < L && (key <= qi || qi >= L)) ? val : -INFINITY;
-        else if (kt >= KTL - 2) val = key < L ? val : -INFINITY;
-        s[kt][r] = val;
-        m = fmaxf(m, val);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[i][ks] = row_frag(ktile, (k0 + i) * 16 + c, ks * 4 + g);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kt = k0 + i;
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][0], qf[0], z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][1], qf[1], z, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          // keys past L can only sit in the last two tiles (KTL = key tiles rounded up to an even count): no test elsewhere
+          if (CAUSAL) z[r] = (key < L && (key <= qi || qi >= L)) ? z[r] : -INFINITY;
+          else if (kt >= KTL - 2) z[r] = key < L ? z[r] : -INFINITY;
+          m = fmaxf(m, z[r]);
+        }
+        s[kt] = z;
       }
+    }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    // exp(x / 8 - max / 8) = exp2(x C1 - max C1): one fma + v_exp_f32 per score; the row is normalised after P V (16 values per
+    // lane instead of 4 KTL), P enters the MFMA as the fp16 value of the un-normalised exponential (<= 1)
+    const float m2 = m * C1;
     float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < KTL; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);
-        s[kt][r] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    if (g == 0 && qi < L) p.lse[((long)n * p.H + h) * L + qi] = (m + __log2f(sum)) * (1.0f / LOG2E);
     h4 pt[KTL];
 #pragma unroll
     for (int kt = 0; kt < KTL; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pt[kt][r] = (half_t)(s[kt][r] * inv);
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], C1, -m2));
+        sum += e;
+        pt[kt][r] = (half_t)e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (g == 0 && qi < L) p.lse[((long)n * p.H + h) * L + qi] = (m2 + __log2f(sum)) * (1.0f / LOG2E);
     // O^T[d][q] = sum_key V[key][d] P[q][key]; k-step ks covers key tiles 2ks, 2ks+1 in permuted order
     f4 acc[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KTL / 2; ++ks)
-        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(vtile, ks * 32, ks * 32 + 16, dt * 16, lane),
-                                                         cat4(pt[2 * ks], pt[2 * ks + 1]), acc[dt], 0, 0, 0);
+    for (int ks = 0; ks < KTL / 2; ++ks) {
+      const h8 pf = cat4(pt[2 * ks], pt[2 * ks + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag_swz(vtile, ks * 32, ks * 32 + 16, dt * 16, lane), pf, acc[dt], 0, 0, 0);
     }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] *= inv;
     store_rows(o, D, acc, q0, L, scr, lane);
     qraw[0] = qnext[0]; qraw[1] = qnext[1];
   }
@@ -342,30 +367,34 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
 
 }  // namespace
 
-template <int KTL, bool CAUSAL>
+// waves per workgroup: as many as share the head's query tiles evenly in two rounds (197 tokens = 13 tiles: 7 waves), at
+// least 4; two workgroups per CU (unpadded K / V images), i.e. 3 - 4 waves per SIMD to overlap one wave's softmax with
+// another's MFMAs
+template <int KTL, int NW, bool CAUSAL>
 static void launch_long_fwd2(const AttnArgs& p, hipStream_t stream) {
-  constexpr int LDS = (2 * 16 * KTL + 4 * 16) * LDS_STRIDE * 2;            // K, V tiles + one 16-row staging tile per wave
+  constexpr int LDS = fwd_lds_bytes(KTL, NW);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
   if (LDS > 64 * 1024) {
     static bool done[HMMC_MAX_DEVICES] = {false};
-    hmmc_allow_lds((const void*)attn_long_fwd_kernel<KTL, CAUSAL>, LDS, done);
+    hmmc_allow_lds((const void*)attn_long_fwd_kernel<KTL, NW, CAUSAL>, LDS, done);
   }
-  hipLaunchKernelGGL((attn_long_fwd_kernel<KTL, CAUSAL>), dim3((unsigned)(p.nseq * p.H)), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL((attn_long_fwd_kernel<KTL, NW, CAUSAL>), dim3((unsigned)(p.nseq * p.H)), dim3(64 * NW), LDS, stream, p);
 }
-template <int KTL>
+template <int KTL, int NW>
 static void launch_long_fwd(const AttnArgs& p, hipStream_t stream) {
-  if (p.causal) launch_long_fwd2<KTL, true>(p, stream); else launch_long_fwd2<KTL, false>(p, stream);
+  if (p.causal) launch_long_fwd2<KTL, NW, true>(p, stream); else launch_long_fwd2<KTL, NW, false>(p, stream);
 }
 
 int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream) {
   if ((long)p.nseq * p.H >= (1l << 31)) return HMMC_ERR_UNSUPPORTED;
   const int ktl = ((p.L + 31) / 32) * 2;                                    // key tiles, rounded up to an even count
   switch (ktl) {
-    case 6: launch_long_fwd<6>(p, stream); break;
-    case 8: launch_long_fwd<8>(p, stream); break;
-    case 10: launch_long_fwd<10>(p, stream); break;
-    case 12: launch_long_fwd<12>(p, stream); break;
-    case 14: launch_long_fwd<14>(p, stream); break;
-    case 16: launch_long_fwd<16>(p, stream); break;
+    case 6: launch_long_fwd<6, 4>(p, stream); break;       // <= 96 tokens: 5-6 query tiles
+    case 8: launch_long_fwd<8, 4>(p, stream); break;
+    case 10: launch_long_fwd<10, 5>(p, stream); break;
+    case 12: launch_long_fwd<12, 6>(p, stream); break;
+    case 14: launch_long_fwd<14, 7>(p, stream); break;     // 197 tokens (ViT-B/16): 13 tiles on 7 waves
+    case 16: launch_long_fwd<16, 8>(p, stream); break;
     default: return HMMC_ERR_UNSUPPORTED;
   }
   return hmmc_launch_status();
