@@ -169,8 +169,14 @@ __global__ __launch_bounds__(64 * NW, fwd_min_waves(KTL, NW)) void attn_long_fwd
 // Nothing is fetched from global memory between the first MFMA and the last, every operand byte is read once per head (the
 // previous three one-wave-per-64-rows kernels read K, V, Q, dO and O about 4 + 4 + 4 times), and S / dP are formed twice
 // instead of three times.
+// 8 halves op[row][8 chunk .. +7] of an image swizzled with swz_tr (conflict-free for ds_read_b128 as well: rows c and c + 8 of a
+// 16-lane group never share a chunk because the two groups of g differ in bit 0 of the chunk)
+__device__ __forceinline__ h8 frag_t(const half_t* tile, int row, int chunk) {
+  return *reinterpret_cast<const h8*>(tile + row * DH + ((chunk ^ swz_tr(row)) << 3));
+}
+
 template <int KTL, int NW, bool CAUSAL>
-__global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(AttnArgs p) {
   constexpr int ROWS = 16 * KTL, NT = 64 * NW, RPP = NT / 8;              // rows per cooperative pass
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -187,11 +193,11 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
   half_t* dk = dq + D;
   half_t* dv = dq + 2 * D;
   half_t* ktile = reinterpret_cast<half_t*>(smem);
-  half_t* vtile = ktile + ROWS * LDS_STRIDE;
-  half_t* qtile = vtile + ROWS * LDS_STRIDE;
-  half_t* dtile = qtile + ROWS * LDS_STRIDE;
-  half_t* scr = dtile + ROWS * LDS_STRIDE + wid * (16 * LDS_STRIDE);
-  float* lse_s = reinterpret_cast<float*>(dtile + ROWS * LDS_STRIDE + NW * 16 * LDS_STRIDE);
+  half_t* vtile = ktile + ROWS * DH;               // four unpadded images, chunk index XORed with swz_tr(row): every one of
+  half_t* qtile = vtile + ROWS * DH;               // them is read both as row fragments and transposed (both conflict-free)
+  half_t* dtile = qtile + ROWS * DH;
+  half_t* scr = dtile + ROWS * DH + wid * (16 * LDS_STRIDE);
+  float* lse_s = reinterpret_cast<float*>(dtile + ROWS * DH + NW * 16 * LDS_STRIDE);
   float* del_s = lse_s + ROWS;
   float* red = del_s + ROWS;                     // [3][NW][64]: every wave's column sums of its dQ / dK / dV tiles
   const bool want_dbias = p.dbias != nullptr;
@@ -211,10 +217,11 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
     const u4v rd = *reinterpret_cast<const u4v*>(dO + (long)rc * D + ch);
     const u4v ro = *reinterpret_cast<const u4v*>(o + (long)rc * D + ch);
     if (ROWS % RPP == 0 || row < ROWS) {
-      *reinterpret_cast<u4v*>(ktile + row * LDS_STRIDE + ch) = in ? rk : z;
-      *reinterpret_cast<u4v*>(vtile + row * LDS_STRIDE + ch) = in ? rv : z;
-      *reinterpret_cast<u4v*>(qtile + row * LDS_STRIDE + ch) = in ? rq : z;
-      *reinterpret_cast<u4v*>(dtile + row * LDS_STRIDE + ch) = in ? rd : z;
+      const int so = row * DH + (((tid & 7) ^ swz_tr(row)) << 3);
+      *reinterpret_cast<u4v*>(ktile + so) = in ? rk : z;
+      *reinterpret_cast<u4v*>(vtile + so) = in ? rv : z;
+      *reinterpret_cast<u4v*>(qtile + so) = in ? rq : z;
+      *reinterpret_cast<u4v*>(dtile + so) = in ? rd : z;
     }
     const h8 hd = __builtin_bit_cast(h8, rd), ho = __builtin_bit_cast(h8, ro);
     float dl = 0.f;
@@ -240,8 +247,8 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
     h8 qf[2], df[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      qf[ks] = *reinterpret_cast<const h8*>(qtile + (qt * 16 + c) * LDS_STRIDE + ks * 32 + 8 * g);
-      df[ks] = *reinterpret_cast<const h8*>(dtile + (qt * 16 + c) * LDS_STRIDE + ks * 32 + 8 * g);
+      qf[ks] = frag_t(qtile, qt * 16 + c, ks * 4 + g);
+      df[ks] = frag_t(dtile, qt * 16 + c, ks * 4 + g);
     }
     const float lq = lse_s[qi], dlq = del_s[qi];
     h4 ds16[KTL];
@@ -250,10 +257,9 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
       h8 kf[2][2], vf[2][2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const half_t* kr = ktile + ((k0 + i) * 16 + c) * LDS_STRIDE + 8 * g;
-        const half_t* vr = vtile + ((k0 + i) * 16 + c) * LDS_STRIDE + 8 * g;
-        kf[i][0] = *reinterpret_cast<const h8*>(kr); kf[i][1] = *reinterpret_cast<const h8*>(kr + 32);
-        vf[i][0] = *reinterpret_cast<const h8*>(vr); vf[i][1] = *reinterpret_cast<const h8*>(vr + 32);
+        const int row = (k0 + i) * 16 + c;
+        kf[i][0] = frag_t(ktile, row, g); kf[i][1] = frag_t(ktile, row, 4 + g);
+        vf[i][0] = frag_t(vtile, row, g); vf[i][1] = frag_t(vtile, row, 4 + g);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
           float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], C1, -lq));
           if (CAUSAL) pv = (key < L && key <= qi) ? pv : 0.f;
           else if (kt >= KTL - 2) pv = key < L ? pv : 0.f;
-          ds16[kt][r] = (half_t)(pv * (dp[r] - dlq) * 0.125f);
+          ds16[kt][r] = (half_t)(pv * (dp[r] - dlq));            // the 1/8 of dS is applied to the 16 results below
         }
       }
     }
@@ -279,8 +285,9 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
       acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KTL / 2; ++ks)
-        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(ktile, ks * 32, ks * 32 + 16, dt * 16, lane),
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag_swz(ktile, ks * 32, ks * 32 + 16, dt * 16, lane),
                                                          cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[dt], 0, 0, 0);
+      acc[dt] *= 0.125f;
     }
     store_rows(dq, ld, acc, qt * 16, L, scr, lane);
     if (want_dbias) add_rounded(csum, acc);        // queries past L are exact zeros (their dS is)
@@ -296,8 +303,8 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
     h8 kf[2], vf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      kf[ks] = *reinterpret_cast<const h8*>(ktile + (kt * 16 + c) * LDS_STRIDE + ks * 32 + 8 * g);
-      vf[ks] = *reinterpret_cast<const h8*>(vtile + (kt * 16 + c) * LDS_STRIDE + ks * 32 + 8 * g);
+      kf[ks] = frag_t(ktile, kt * 16 + c, ks * 4 + g);
+      vf[ks] = frag_t(vtile, kt * 16 + c, ks * 4 + g);
     }
     f4 av[4], ak[4];
 #pragma unroll
@@ -310,18 +317,16 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {                // both query tiles of the pair: fragments, lse and delta requested together
         const int qt = 2 * qp + e;
-        const half_t* qr = qtile + (qt * 16 + c) * LDS_STRIDE + 8 * g;
-        const half_t* dr_ = dtile + (qt * 16 + c) * LDS_STRIDE + 8 * g;
-        qf[e][0] = *reinterpret_cast<const h8*>(qr); qf[e][1] = *reinterpret_cast<const h8*>(qr + 32);
-        df[e][0] = *reinterpret_cast<const h8*>(dr_); df[e][1] = *reinterpret_cast<const h8*>(dr_ + 32);
+        qf[e][0] = frag_t(qtile, qt * 16 + c, g); qf[e][1] = frag_t(qtile, qt * 16 + c, 4 + g);
+        df[e][0] = frag_t(dtile, qt * 16 + c, g); df[e][1] = frag_t(dtile, qt * 16 + c, 4 + g);
         lr[e] = *reinterpret_cast<const f4*>(lse_s + qt * 16 + 4 * g);
         dl[e] = *reinterpret_cast<const f4*>(del_s + qt * 16 + 4 * g);
       }
       h8 dT[4], qT[4];                             // dO^T / Q^T of the pair, used after the exponentials
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dT[dt] = tr_frag(dtile, qp * 32, qp * 32 + 16, dt * 16, lane);
-        qT[dt] = tr_frag(qtile, qp * 32, qp * 32 + 16, dt * 16, lane);
+        dT[dt] = tr_frag_swz(dtile, qp * 32, qp * 32 + 16, dt * 16, lane);
+        qT[dt] = tr_frag_swz(qtile, qp * 32, qp * 32 + 16, dt * 16, lane);
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
           float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], C1, -lr[e][r]));   // 0 for queries past L (lse = +inf)
           pv = (key_ok && (!CAUSAL || key <= qi)) ? pv : 0.f;
           p16[e][r] = (half_t)pv;
-          ds16[e][r] = (half_t)(pv * (dp[r] - dl[e][r]) * 0.125f);
+          ds16[e][r] = (half_t)(pv * (dp[r] - dl[e][r]));         // the 1/8 of dS is applied to dK below
         }
       }
 #pragma unroll
@@ -346,6 +351,8 @@ __global__ __launch_bounds__(64 * NW) void attn_long_bwd_kernel(AttnArgs p) {
         ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qT[dt], cat4(ds16[0], ds16[1]), ak[dt], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ak[dt] *= 0.125f;
     store_rows(dv, ld, av, kt * 16, L, scr, lane);
     store_rows(dk, ld, ak, kt * 16, L, scr, lane);
     if (want_dbias) { add_rounded(csum, av); add_rounded(csk, ak); }   // keys past L are exact zeros (P and dS are)
@@ -402,8 +409,8 @@ int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream) {
 
 template <int KTL, int NW, bool CAUSAL>
 static void launch_long_bwd2(const AttnArgs& p, hipStream_t stream) {
-  constexpr int LDS = (4 * 16 * KTL + NW * 16) * LDS_STRIDE * 2 + 2 * 16 * KTL * 4     // K, V, Q, dO + staging per wave + lse, delta
-                      + 3 * NW * 64 * 4;                                                // + the waves' column sums
+  constexpr int LDS = 4 * 16 * KTL * DH * 2 + NW * 16 * LDS_STRIDE * 2 + 2 * 16 * KTL * 4   // K, V, Q, dO images + staging per wave + lse, delta
+                      + 3 * NW * 64 * 4;                                                 // + the waves' column sums
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool done[HMMC_MAX_DEVICES] = {false};
   hmmc_allow_lds((const void*)attn_long_bwd_kernel<KTL, NW, CAUSAL>, LDS, done);
@@ -418,12 +425,15 @@ int hmmc_attention_long_bwd(const AttnArgs& p, hipStream_t stream) {
   if ((long)p.nseq * p.H >= (1l << 31) || !p.out) return HMMC_ERR_UNSUPPORTED;
   const int ktl = ((p.L + 31) / 32) * 2;
   switch (ktl) {
-    case 6: launch_long_bwd<6, 8>(p, stream); break;
+    // 8 waves (two per SIMD, up to 256 registers each: phase 2 holds 64 accumulator + 64 transposed-operand registers).  One wave
+    // per tile - 13 waves for ViT-B/16's 13 tiles - would need 128 registers per wave and spills ~100 of them; 7 waves (13 tiles
+    // in two even rounds) measured the same as 8 (480 vs 487 us at 384 x 197 x 12).
+    case 6: launch_long_bwd<6, 6>(p, stream); break;
     case 8: launch_long_bwd<8, 8>(p, stream); break;
     case 10: launch_long_bwd<10, 8>(p, stream); break;
     case 12: launch_long_bwd<12, 8>(p, stream); break;
     case 14: launch_long_bwd<14, 8>(p, stream); break;
-    case 16: launch_long_bwd<16, 4>(p, stream); break;     // 4 x 36 KiB of operands: only four staging tiles fit beside them
+    case 16: launch_long_bwd<16, 8>(p, stream); break;
     default: return HMMC_ERR_UNSUPPORTED;
   }
   return hmmc_launch_status();
