@@ -262,13 +262,17 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
         input_ids[rnd] = words[rnd]
         return (input_ids, targets) if targets is not None else input_ids
 
-    def get_mlm_loss(self, input_ids, input_mask):
+    def _mlm_inputs(self, input_ids):
+        """masked ids and labels of the MLM pass (the first half of get_mlm_loss, reference modules/modeling.py:160-165)"""
         ids = input_ids.clone()
         labels = ids.clone()
         prob = torch.full(labels.shape, self.mlm_probability)
         # random replacement ids are drawn from the rows the embedding table really has (VOCAB for CLIP's tokenizer)
         vocab = self.text_encoder.token_embedding.weight.shape[0]
-        ids, labels = self.mask(ids, vocab, input_mask.device, targets=labels, probability_matrix=prob)
+        return self.mask(ids, vocab, input_ids.device, targets=labels, probability_matrix=prob)
+
+    def get_mlm_loss(self, input_ids, input_mask):
+        ids, labels = self._mlm_inputs(input_ids)
         hidden = self.text_encoder(ids, input_mask, return_hidden=True)
         return self.calculate_mlm_loss(hidden, labels, _label_density=float(self.mlm_probability))
 
@@ -291,24 +295,41 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
             return None
         bird = self.task_config.dataset == "bird"
         overlap = _OVERLAP_TOWERS and video.is_cuda
+        # Text passes that share weights share ONE pass of the tower (TextEncoder.encode_many): the online title pass with the
+        # MLM pass of the masked titles (the reference runs the latter after the enqueue, :413-416; the online weights do not
+        # change in between and the mask's random draws are the only consumer of the host generator in this function), and the
+        # two momentum passes.  The `bird` branches (unreachable from main_pretrain.py) keep separate passes.
+        mlm_hidden = mlm_labels = None
+        if not bird:
+            mlm_ids, mlm_labels = self._mlm_inputs(title_ids)
+
+        def online_text():
+            if bird:
+                return self.text_encoder(tag_ids, tag_mask), self.text_encoder(title_ids, title_mask), None
+            title, hidden = self.text_encoder.encode_many([title_ids, mlm_ids], ["feat", "hidden"])
+            return None, title, hidden
+
+        def key_text():
+            if bird:
+                return self.text_encoder_k(tag_ids, tag_mask), self.text_encoder_k(title_ids, title_mask)
+            return self.text_encoder_k.encode_many([tag_ids, title_ids], ["feat", "feat"])
         if overlap:
             # The text towers (online title / tag features, momentum text encoder) run on a side stream beside the two frame
             # towers; the momentum pass waits for the EMA update, which stays on the main stream.  Autograd replays each
-            # backward on its forward stream.  The MLM pass is NOT moved: its 49 408-way fp32 head is a long kernel of many
-            # small workgroups which, run beside the frame tower, keeps the persistent 128 KiB-LDS GEMM workgroups from
-            # becoming resident (measured: 105.6 vs 101.7 ms per step).
+            # backward on its forward stream.  The MLM HEAD is not moved (only the masked titles' pass through the text tower
+            # rides with the title pass): its 49 408-way fp32 GEMM is a long kernel of many small workgroups which, run beside
+            # the frame tower, keeps the persistent 128 KiB-LDS GEMM workgroups from becoming resident (measured: 105.6 vs
+            # 101.7 ms per step).
             cur = torch.cuda.current_stream(video.device)
             side = _side_stream(video.device)
             side.wait_stream(cur)
-            for t in (tag_ids, tag_mask, title_ids, title_mask):
+            for t in (tag_ids, tag_mask, title_ids, title_mask) + (() if bird else (mlm_ids,)):
                 t.record_stream(side)
             with torch.cuda.stream(side):
-                tag_fea = self.text_encoder(tag_ids, tag_mask) if bird else None
-                title_fea = self.text_encoder(title_ids, title_mask)
+                tag_fea, title_fea, mlm_hidden = online_text()
         v_fea, frame_fea = self.visual_encoder(video, video_frame)
         if not overlap:
-            tag_fea = self.text_encoder(tag_ids, tag_mask) if bird else None
-            title_fea = self.text_encoder(title_ids, title_mask)
+            tag_fea, title_fea, mlm_hidden = online_text()
         bs, frame, hidden = frame_fea.shape
         frame_proj = self._mlp(self.v_projector, frame_fea.reshape(-1, hidden))
         frame_pred = self._mlp(self.v_predictor, frame_proj).view(bs, frame, hidden)
@@ -320,16 +341,14 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
                 ema_done.record(cur)
                 side.wait_event(ema_done)
                 with torch.cuda.stream(side):
-                    tag_fea_k = self.text_encoder_k(tag_ids, tag_mask)
-                    title_fea_k = self.text_encoder_k(title_ids, title_mask)
+                    tag_fea_k, title_fea_k = key_text()
             else:
-                tag_fea_k = self.text_encoder_k(tag_ids, tag_mask)
-                title_fea_k = self.text_encoder_k(title_ids, title_mask)
+                tag_fea_k, title_fea_k = key_text()
             v_fea_k, frame_fea_k = self.visual_encoder_k(video, video_frame)
             frame_proj_k = self._mlp(self.v_projector_k, frame_fea_k.reshape(-1, hidden)).view(bs, frame, hidden)
         if overlap:
             cur.wait_stream(side)
-            for t in (tag_fea, title_fea, tag_fea_k, title_fea_k):
+            for t in (tag_fea, title_fea, tag_fea_k, title_fea_k, mlm_hidden):
                 if t is not None:
                     t.record_stream(cur)
         # The losses (and their backward, which runs after the enqueue below) must see the OLD negatives: one
@@ -353,8 +372,10 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
             else:
                 loss_FTM = ft
         self._dequeue_and_enqueue(v_fea_k, tag_fea_k, title_fea_k, frame_fea_k, frame_proj_k)
-        mlm = self.get_mlm_loss(title_ids, title_mask)
-        loss_MLM = (self.get_mlm_loss(tag_ids, tag_mask) + mlm) / 2 if bird else mlm
+        if bird:
+            loss_MLM = (self.get_mlm_loss(tag_ids, tag_mask) + self.get_mlm_loss(title_ids, title_mask)) / 2
+        else:
+            loss_MLM = self.calculate_mlm_loss(mlm_hidden, mlm_labels, _label_density=float(self.mlm_probability))
         self.last_losses = (loss_FAM, loss_VTM, loss_FTM, loss_MLM)
         loss = self.weight_FAM * loss_FAM + self.weight_VTM * loss_VTM + self.weight_FTM * loss_FTM + self.weight_MLM * loss_MLM
         if self.rank == 0 and getattr(self.task_config, "logdir", None):

@@ -194,6 +194,39 @@ class TextEncoder(nn.Module):
         return feat
 
 
+def _encode_many(self, texts, wants):
+    """Several id tensors [b_i, L_i] through ONE pass of the text tower (padded with id 0 to the longest; the tower is
+    causal and its rows independent, so every sequence's feature / hidden states are those of its own pass): one set of
+    ~600 small launches instead of one per input, and ONE gradient per parameter where separate passes make autograd
+    add two (the pre-training step runs the online title pass and the MLM pass of the masked titles on the same
+    weights, modules/modeling.py:347-352,160-169, and two momentum passes, :369-373).
+    wants[i]: "feat" -> [b_i, 512] (EOT row), "hidden" -> [b_i, L_i, 512]."""
+    Lmax = max(t.shape[1] for t in texts)
+    if Lmax > self.positional_embedding.shape[0]:
+        raise ValueError("sequence longer than the positional embedding table")
+    ids = torch.cat([t if t.shape[1] == Lmax else torch.nn.functional.pad(t, (0, Lmax - t.shape[1])) for t in texts], dim=0)
+    x = Fn.TextEmbedFn.apply(ids, self.token_embedding.weight, self.positional_embedding, self.dtype)
+    x = self.transformer(x, ids.shape[0], Lmax)
+    outs, row0 = [], 0
+    for t, want in zip(texts, wants):
+        b, L = t.shape
+        seq = torch.arange(row0, row0 + b, device=t.device)
+        if want == "feat":
+            idx = (seq * Lmax + t.argmax(dim=-1)).to(torch.int32)                # EOT = largest id
+            outs.append(Fn.LnProjFn.apply(x, idx, self.ln_final.weight, self.ln_final.bias, self.text_projection))
+        elif L == Lmax:
+            rows = x[row0 * Lmax:(row0 + b) * Lmax]
+            outs.append(Fn.LnProjFn.apply(rows, None, self.ln_final.weight, self.ln_final.bias, self.text_projection).view(b, L, -1))
+        else:
+            idx = (seq[:, None] * Lmax + torch.arange(L, device=t.device)[None, :]).reshape(-1).to(torch.int32)
+            outs.append(Fn.LnProjFn.apply(x, idx, self.ln_final.weight, self.ln_final.bias, self.text_projection).view(b, L, -1))
+        row0 += b
+    return outs
+
+
+TextEncoder.encode_many = _encode_many
+
+
 class BertLayerNorm(LayerNorm):
     pass
 
