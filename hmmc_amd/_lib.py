@@ -20,6 +20,8 @@ SIGNATURES = {
     "hmmc_gemm_f16_workspace": ("iii", "z"),
     "hmmc_gemm_f16_colsum_rows": ("iii", "z"),
     "hmmc_gemm_f16": ("pppiiiiiiiippppipzp", "i"),
+    "hmmc_gemm_f16_wgrad_group_workspace": ("ppii", "z"),
+    "hmmc_gemm_f16_wgrad_group": ("pppppiipzp", "i"),
     "hmmc_gemm_reserve_cus": ("i", "i"),
     "hmmc_gemm_profile_start": ("", "i"),
     "hmmc_gemm_profile_stop": ("pppp", "i"),

@@ -51,6 +51,14 @@ struct GemmArgs {
   unsigned a_bytes, b_bytes;
 };
 
+// Grouped weight gradients: up to four problems dW_j[M_j, N_j] = dY_j^T X_j over the SAME token range (K = tokens) in one
+// persistent launch.  An item is (K split, problem, tile); all problems share nkt and the split, so the four weight
+// gradients of a layer fill the chip together (108 tiles at ViT-B/32: split 7 = 756 items = 2.95 rounds) instead of one
+// after the other with a partial last round and a split chosen for 9-36 tiles each.  Slabs: [problem][split][M_j][N_j] fp32.
+constexpr int GROUP_MAX = 4;
+struct GroupProb { const half_t* A; const half_t* B; int lda, ldb, M, N; unsigned a_bytes, b_bytes; int ntn; int pad_; long slab_off; };
+struct GemmGroup { int n; int tile0[GROUP_MAX + 1]; GroupProb pr[GROUP_MAX]; };
+
 // ---- LDS-DMA staging -------------------------------------------------------------------------
 // k-major tile image: [128 rows][8 chunks of 16 B]; phys chunk = logical ^ ((row >> 1) & 7)
 // m-major tile image: [64 k-rows][16 chunks of 16 B]; phys chunk = logical ^ f(krow),
@@ -374,16 +382,16 @@ __device__ __forceinline__ void epilogue_f16(const GemmArgs& p, f4 (&acc)[MT][4]
 
 // split-K partial sums: fp32 slab [split][M][N], 16-byte stores straight from the MFMA layout
 template <int MT, int NT>
-__device__ __forceinline__ void epilogue_slab(const GemmArgs& p, f4 (&acc)[MT][NT], int mrow, int ncol, int split) {
-  float* ws = p.ws + (size_t)split * p.M * p.N;
+__device__ __forceinline__ void epilogue_slab(float* slab0, int M, int N, f4 (&acc)[MT][NT], int mrow, int ncol, int split) {
+  float* ws = slab0 + (size_t)split * M * N;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     int m = mrow + i * 16;
-    if (m >= p.M) continue;
+    if (m >= M) continue;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       int n = ncol + j * 16;
-      if (n < p.N) *reinterpret_cast<f4*>(ws + (size_t)m * p.N + n) = acc[i][j];
+      if (n < N) *reinterpret_cast<f4*>(ws + (size_t)m * N + n) = acc[i][j];
     }
   }
 }
@@ -392,8 +400,8 @@ __device__ __forceinline__ void epilogue_slab(const GemmArgs& p, f4 (&acc)[MT][N
 // Persistent: the grid is sized to the chip and every workgroup walks work items (output tile x K-split)
 // item, item + gridDim, ...  The LDS-DMA prefetch runs one K-tile ahead across item boundaries, so the
 // first tile of the next output tile is already in flight while this one's epilogue stores drain.
-template <bool AK, bool BK, int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
+template <bool AK, bool BK, int BM, int BN, int WM, int WN, int EPI, bool GRP>
+__device__ __forceinline__ void gemm_f16_body(const GemmArgs& p, const GemmGroup& gp) {
   constexpr int NTH = 64 * WM * WN;
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
   constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -410,9 +418,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int ntn = (p.N + BN - 1) / BN;
   const int ntm = (p.M + BM - 1) / BM;
-  const int ntiles = ntn * ntm;
+  const int ntiles = GRP ? gp.tile0[gp.n] : ntn * ntm;
   const int nitems = ntiles * p.splitk;
   const int nkt = (p.K + BKT - 1) / BKT;
+  // (split, problem, tile row, tile column) of a work item; one problem unless GRP
+  auto decode = [&](int it, int& sp, int& pj, int& tm_, int& tn_) {
+    sp = it / ntiles;
+    int t2 = it - sp * ntiles;
+    if constexpr (GRP) {
+      pj = 0;
+#pragma unroll
+      for (int j = 1; j < GROUP_MAX; ++j) pj = (j < gp.n && t2 >= gp.tile0[j]) ? j : pj;
+      t2 -= gp.tile0[pj];
+      const int w = gp.pr[pj].ntn;
+      tm_ = t2 / w; tn_ = t2 - tm_ * w;
+    } else {
+      pj = 0;
+      tm_ = t2 / ntn; tn_ = t2 - tm_ * ntn;
+    }
+  };
 
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
@@ -429,8 +453,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
   // current position (item, kt) and the decoded tile of the item
   int item = lid;
   if (item >= nitems) return;
-  int split = item / ntiles, tile = item - split * ntiles;
-  int tm = tile / ntn, tn = tile - tm * ntn;
+  int split, cprob, tm, tn;
+  decode(item, split, cprob, tm, tn);
   int kt = split * p.ktps, kt_end = min(nkt, kt + p.ktps);     // host guarantees kt < kt_end for every item
   int buf = 0;
 #if HMMC_DBG >= 3
@@ -447,14 +471,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
     stage_tile<BK, BN, NTH>(rb, smem + A_BYTES, wid, tid, tn * BN, kt * BKT, p.ldb);
   }
 
+  int n_prob = 0;
   auto next_pos = [&](int& n_item, int& n_split, int& n_tm, int& n_tn, int& n_kt, int& n_end) {
-    n_item = item; n_split = split; n_tm = tm; n_tn = tn; n_kt = kt + 1; n_end = kt_end;
+    n_item = item; n_split = split; n_tm = tm; n_tn = tn; n_kt = kt + 1; n_end = kt_end; n_prob = cprob;
     if (n_kt >= kt_end) {
       n_item = item + nblk;
       if (n_item < nitems) {
-        n_split = n_item / ntiles;
-        int t2 = n_item - n_split * ntiles;
-        n_tm = t2 / ntn; n_tn = t2 - n_tm * ntn;
+        decode(n_item, n_split, n_prob, n_tm, n_tn);
         n_kt = n_split * p.ktps; n_end = min(nkt, n_kt + p.ktps);
       }
     }
@@ -466,8 +489,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
 #if HMMC_DBG == 2 || HMMC_DBG == 5
     _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(acc[i][j]));
 #else
-    if (p.splitk > 1 || p.slab)
-      epilogue_slab<MT, NT>(p, acc, tm * BM + wm * (MT * 16) + (lane & 15), tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
+    if constexpr (GRP)
+      epilogue_slab<MT, NT>(p.ws + gp.pr[cprob].slab_off, gp.pr[cprob].M, gp.pr[cprob].N, acc, tm * BM + wm * (MT * 16) + (lane & 15),
+                            tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
+    else if (p.splitk > 1 || p.slab)
+      epilogue_slab<MT, NT>(p.ws, p.M, p.N, acc, tm * BM + wm * (MT * 16) + (lane & 15), tn * BN + wn * (NT * 16) + 4 * (lane >> 4), split);
     else
       epilogue_f16<MT, EPI>(p, acc, tm * BM + wm * (MT * 16), tn * BN + wn * (NT * 16), lane, smem + 2 * STAGE_BYTES + wid * EPI_LDS_PER_WAVE);
 #endif
@@ -503,7 +529,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
     // last K-tile the DMA is still issued, out of range (reads as zero into a dead image), so the count stays exact;
     // epilogue stores only make the wait stricter.
     constexpr int HALF = 128 * BKT * 2;
-    const unsigned vA = half_vbase<AK, true>(tid, p.lda), vB = half_vbase<BK, false>(tid, p.ldb);
+    // operands of the problem being STAGED (the prefetch runs ahead of the computation across item boundaries, so under GRP
+    // it can already be in the next problem); without GRP these never change
+    unsigned vA = half_vbase<AK, true>(tid, p.lda), vB = half_vbase<BK, false>(tid, p.ldb);
+    int s_lda = p.lda, s_ldb = p.ldb;
+    auto s_bind = [&](int pj) {
+      if constexpr (GRP) {
+        const GroupProb& q = gp.pr[pj];
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)q.A, 0, (int)q.a_bytes, 0x00020000);
+        rb = __builtin_amdgcn_make_buffer_rsrc((void*)q.B, 0, (int)q.b_bytes, 0x00020000);
+        s_lda = q.lda; s_ldb = q.ldb;
+        vA = half_vbase<AK, true>(tid, s_lda); vB = half_vbase<BK, false>(tid, s_ldb);
+      }
+    };
+    s_bind(cprob);
     int s_item = item, s_tm = tm, s_tn = tn, s_kt = kt, s_end = kt_end, s_buf = 0;
     bool s_ok = true;
     auto s_advance = [&]() {
@@ -512,23 +551,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
         s_item += nblk;
         s_ok = s_item < nitems;
         if (s_ok) {
-          int sp = s_item / ntiles, t2 = s_item - sp * ntiles;
-          s_tm = t2 / ntn; s_tn = t2 - s_tm * ntn;
+          int sp, pj;
+          decode(s_item, sp, pj, s_tm, s_tn);
+          s_bind(pj);
           s_kt = sp * p.ktps; s_end = min(nkt, s_kt + p.ktps);
         }
       }
     };
     auto stage_a = [&](int h) {
-      unsigned so = AK ? ((unsigned)(s_tm * BM + h * 64) * (unsigned)p.lda + (unsigned)(s_kt * BKT)) * 2u
-                       : ((unsigned)(s_kt * BKT) * (unsigned)p.lda + (unsigned)(s_tm * BM + h * 64)) * 2u;
+      unsigned so = AK ? ((unsigned)(s_tm * BM + h * 64) * (unsigned)s_lda + (unsigned)(s_kt * BKT)) * 2u
+                       : ((unsigned)(s_kt * BKT) * (unsigned)s_lda + (unsigned)(s_tm * BM + h * 64)) * 2u;
       if (!s_ok) so = 0x80000000u;
-      stage_half<AK>(ra, smem + s_buf * (4 * HALF) + h * HALF, wid, vA, so, p.lda);
+      stage_half<AK>(ra, smem + s_buf * (4 * HALF) + h * HALF, wid, vA, so, s_lda);
     };
     auto stage_b = [&](int h) {
-      unsigned so = BK ? ((unsigned)(s_tn * BN + h * 32) * (unsigned)p.ldb + (unsigned)(s_kt * BKT)) * 2u
-                       : ((unsigned)(s_kt * BKT) * (unsigned)p.ldb + (unsigned)(s_tn * BN + h * 32)) * 2u;
+      unsigned so = BK ? ((unsigned)(s_tn * BN + h * 32) * (unsigned)s_ldb + (unsigned)(s_kt * BKT)) * 2u
+                       : ((unsigned)(s_kt * BKT) * (unsigned)s_ldb + (unsigned)(s_tn * BN + h * 32)) * 2u;
       if (!s_ok) so = 0x80000000u;
-      stage_half<BK>(rb, smem + s_buf * (4 * HALF) + (2 + h) * HALF, wid, vB, so, p.ldb);
+      stage_half<BK>(rb, smem + s_buf * (4 * HALF) + (2 + h) * HALF, wid, vB, so, s_ldb);
     };
 #define HMMC_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); \
                         __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -618,7 +658,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
         if (wm == 1 && n_item < nitems) HMMC_BAR();
       }
       if (n_item >= nitems) break;
-      item = n_item; split = n_split; tm = n_tm; tn = n_tn; kt = n_kt; kt_end = n_end;
+      item = n_item; split = n_split; tm = n_tm; tn = n_tn; kt = n_kt; kt_end = n_end; cprob = n_prob;
       buf ^= 1;
     }
 #undef HMMC_BAR
@@ -670,6 +710,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
       item = n_item; split = n_split; tm = n_tm; tn = n_tn; kt = n_kt; kt_end = n_end;
       buf ^= 1;
     }
+  }
+}
+
+template <bool AK, bool BK, int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16_kernel(GemmArgs p) {
+  gemm_f16_body<AK, BK, BM, BN, WM, WN, EPI, false>(p, GemmGroup{});
+}
+// the grouped weight-gradient launch (m-major operands, 256x256 tiles, slabs only)
+__global__ __launch_bounds__(512, 2) void gemm_f16_wgrad_group_kernel(GemmArgs p, GemmGroup gp) {
+  gemm_f16_body<false, false, 256, 256, 2, 4, 0, true>(p, gp);
+}
+
+// the slabs of a grouped launch -> the fp16 results: problem j, element e of its [M_j][N_j]
+struct GroupOut { half_t* C[GROUP_MAX]; long slab_off[GROUP_MAX]; long elems[GROUP_MAX + 1]; int N[GROUP_MAX], ldc[GROUP_MAX]; int n, S; };
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* __restrict__ ws, GroupOut go) {
+  const long total4 = go.elems[go.n] / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;
+    int j = 0;
+#pragma unroll
+    for (int t = 1; t < GROUP_MAX; ++t) j = (t < go.n && e >= go.elems[t]) ? t : j;
+    const long le = e - go.elems[j], slab = go.elems[j + 1] - go.elems[j];
+    const float* src = ws + go.slab_off[j] + le;
+    f4 s = *reinterpret_cast<const f4*>(src);
+    for (int k = 1; k < go.S; ++k) s += *reinterpret_cast<const f4*>(src + k * slab);
+    const int m = (int)(le / go.N[j]), n = (int)(le - (long)m * go.N[j]);
+    h4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (half_t)s[r];
+    *reinterpret_cast<h4*>(go.C[j] + (size_t)m * go.ldc[j] + n) = o;
   }
 }
 
@@ -922,6 +992,105 @@ static int gemm_f16_one(const void* A, const void* B, void* C, int M, int N, int
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, (half_t*)C, M, N,
                        ldc, splitk);
   }
+  if (rec.e0) { (void)hipEventRecord(rec.e1, stream); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(rec); }
+  return hmmc_launch_status();
+}
+
+// ---- grouped weight gradients ---------------------------------------------------------------------------------------------
+// dW_j[Np_j, Kp_j] = dY_j[T, Np_j]^T X_j[T, Kp_j], j < nprob <= 4, in ONE persistent launch + one reduce (see GemmGroup).
+namespace {
+struct GroupPlan { int splitk, ktps; long tiles, elems; };
+// K split of a grouped launch: the estimated time of rounds x (K-tiles per item + fixed cost per item) plus the slab round
+// trip, with the measured constants of the m-major K loop (1.97 us per K-tile, ~8 us per item, ~5 TB/s for the slabs)
+GroupPlan group_plan(const int* Np, const int* Kp, int nprob, int T) {
+  GroupPlan g{1, 1, 0, 0};
+  for (int j = 0; j < nprob; ++j) {
+    g.tiles += (long)((Np[j] + 255) / 256) * ((Kp[j] + 255) / 256);
+    g.elems += (long)Np[j] * Kp[j];
+  }
+  const int nkt = (T + BKT - 1) / BKT;
+  const int cus = gemm_cus();
+  double best = 1e30;
+  for (int s = 1; s <= 64 && s * 4 <= nkt; ++s) {
+    const long items = g.tiles * s;
+    const long rounds = (items + cus - 1) / cus;
+    const int kti = (nkt + s - 1) / s;
+    const double t = rounds * (kti * 1.97 + 8.0) + (s > 0 ? 8.0 * s * g.elems / 5.0e6 : 0.0);
+    if (t < best) { best = t; g.splitk = s; }
+  }
+  g.ktps = (nkt + g.splitk - 1) / g.splitk;
+  g.splitk = (nkt + g.ktps - 1) / g.ktps;
+  return g;
+}
+bool group_ok(const int* Np, const int* Kp, int nprob, int T) {
+  static const bool off = std::getenv("HMMC_NO_WGRAD_GROUP") != nullptr;       // A/B runs: one launch per gradient, as before round 3
+  if (off) return false;
+  if (!Np || !Kp || nprob < 1 || nprob > GROUP_MAX || T < 2048) return false;
+  for (int j = 0; j < nprob; ++j) {
+    if (Np[j] < 256 || Kp[j] < 256 || (Np[j] % 256) || (Kp[j] % 256)) return false;       // 256x256 tiles only
+    if ((uint64_t)(T + BKT) * (uint64_t)(Np[j] > Kp[j] ? Np[j] : Kp[j]) * 2 >= PIECE_BYTES) return false;   // 32-bit offsets
+  }
+  return true;
+}
+}  // namespace
+
+// workspace bytes of hmmc_gemm_f16_wgrad_group, or 0 when these shapes should take one hmmc_gemm_f16 call per gradient
+extern "C" size_t hmmc_gemm_f16_wgrad_group_workspace(const int* Np, const int* Kp, int nprob, int T) {
+  if (!group_ok(Np, Kp, nprob, T)) return 0;
+  const GroupPlan g = group_plan(Np, Kp, nprob, T);
+  return (size_t)g.splitk * g.elems * sizeof(float);
+}
+
+extern "C" int hmmc_gemm_f16_wgrad_group(const void* const* dY, const void* const* X, void* const* dW, const int* Np,
+                                         const int* Kp, int nprob, int T, void* workspace, size_t ws_bytes, hipStream_t stream) {
+  if (!dY || !X || !dW || !group_ok(Np, Kp, nprob, T)) return HMMC_ERR_UNSUPPORTED;
+  const GroupPlan g = group_plan(Np, Kp, nprob, T);
+  if (!workspace || ws_bytes < (size_t)g.splitk * g.elems * sizeof(float)) return HMMC_ERR_WORKSPACE;
+  GemmGroup gp{};
+  GroupOut go{};
+  gp.n = go.n = nprob;
+  go.S = g.splitk;
+  long tile0 = 0, off = 0, e0 = 0;
+  double flops = 0, bytes = 0;
+  for (int j = 0; j < nprob; ++j) {
+    if (!dY[j] || !X[j] || !dW[j] || (((uintptr_t)dY[j] | (uintptr_t)X[j] | (uintptr_t)dW[j]) & 15)) return HMMC_ERR_ARG;
+    GroupProb& q = gp.pr[j];
+    q.A = (const half_t*)dY[j]; q.B = (const half_t*)X[j];
+    q.lda = Np[j]; q.ldb = Kp[j]; q.M = Np[j]; q.N = Kp[j];
+    q.a_bytes = (unsigned)(((uint64_t)(T - 1) * Np[j] + Np[j]) * 2);
+    q.b_bytes = (unsigned)(((uint64_t)(T - 1) * Kp[j] + Kp[j]) * 2);
+    q.ntn = (Kp[j] + 255) / 256;
+    q.slab_off = off;
+    gp.tile0[j] = (int)tile0;
+    go.C[j] = (half_t*)dW[j]; go.slab_off[j] = off; go.elems[j] = e0; go.N[j] = Kp[j]; go.ldc[j] = Kp[j];
+    tile0 += (long)((Np[j] + 255) / 256) * q.ntn;
+    off += (long)g.splitk * Np[j] * Kp[j];
+    e0 += (long)Np[j] * Kp[j];
+    flops += 2.0 * Np[j] * Kp[j] * (double)T;
+    bytes += 2.0 * ((double)T * Np[j] + (double)T * Kp[j] + (double)Np[j] * Kp[j]);
+  }
+  gp.tile0[nprob] = (int)tile0;
+  go.elems[nprob] = e0;
+  GemmArgs p{};
+  p.A = gp.pr[0].A; p.B = gp.pr[0].B; p.C = nullptr;
+  p.M = Np[0]; p.N = Kp[0]; p.K = T; p.lda = Np[0]; p.ldb = Kp[0]; p.ldc = Kp[0];
+  p.flags = 0; p.splitk = g.splitk; p.ktps = g.ktps; p.slab = 1;
+  p.a_bytes = gp.pr[0].a_bytes; p.b_bytes = gp.pr[0].b_bytes;
+  p.ws = (float*)workspace;
+  const long items = tile0 * g.splitk;
+  const int cus = gemm_cus();
+  constexpr int SMEM = 2 * (256 + 256) * BKT * 2 + 8 * EPI_LDS_PER_WAVE;
+  static bool done[HMMC_MAX_DEVICES] = {false};
+  hmmc_allow_lds((const void*)gemm_f16_wgrad_group_kernel, SMEM, done);
+  GemmProfRec rec{};
+  if (g_prof_on) {
+    (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
+    rec.flops = flops; rec.bytes = bytes; rec.layout = 2;
+    (void)hipEventRecord(rec.e0, stream);
+  }
+  hipLaunchKernelGGL(gemm_f16_wgrad_group_kernel, dim3((unsigned)(items < cus ? items : cus)), dim3(512), SMEM, stream, p, gp);
+  const size_t nb = ((size_t)e0 / 4 + 255) / 256;
+  hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, stream, (const float*)workspace, go);
   if (rec.e0) { (void)hipEventRecord(rec.e1, stream); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(rec); }
   return hmmc_launch_status();
 }

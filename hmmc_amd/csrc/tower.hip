@@ -34,6 +34,9 @@ size_t hmmc_colsum_workspace(int, int);
 int hmmc_attention_f16_fwd(const void*, void*, float*, int, int, int, int, hipStream_t);
 int hmmc_attention_f16_bwd(const void*, const void*, const float*, const void*, void*, float*, int, int, int, int, hipStream_t);
 size_t hmmc_gemm_f16_colsum_rows(int, int, int);
+size_t hmmc_gemm_f16_wgrad_group_workspace(const int*, const int*, int, int);
+int hmmc_gemm_f16_wgrad_group(const void* const*, const void* const*, void* const*, const int*, const int*, int, int, void*, size_t,
+                              hipStream_t);
 int hmmc_temporal_attention_fwd(const float*, float*, float*, int, int, int, int, hipStream_t);
 int hmmc_temporal_attention_bwd(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
 }
@@ -109,10 +112,13 @@ extern "C" size_t hmmc_tower_act_bytes(long tokens, int D, int nseq, int L, int 
   return carve(nullptr, tokens, D, nseq, L, heads, fp32 ? 4 : 2, fp32 != 0).bytes;
 }
 
-// transient gradients of the backward: dh [T,4D], dqkv [T,3D], dln [T,D], dx1 [T,D], ping/pong dx [T,D] x2
+// transient gradients of the backward: dh [T,4D], dqkv [T,3D], dln [T,D], dx1 [T,D], ping/pong dx [T,D] x2; the fp16 tower holds
+// dh / dqkv / dx1 twice (layers alternate): a layer's grouped weight-gradient launch reads them while the next layer's chain
+// already writes its own
 extern "C" size_t hmmc_tower_bwd_scratch_bytes(long tokens, int D, int fp32) {
   size_t es = fp32 ? 4 : 2;
-  return al((size_t)tokens * 4 * D * es) + al((size_t)tokens * 3 * D * es) + 4 * al((size_t)tokens * D * es);
+  const size_t set = al((size_t)tokens * 4 * D * es) + al((size_t)tokens * 3 * D * es) + al((size_t)tokens * D * es);
+  return (fp32 ? 1 : 2) * set + 3 * al((size_t)tokens * D * es);
 }
 
 // fp32 partial sums of the fp16 tower's deferred reductions, one slot per layer (hmmc_tower_bwd reduces all of them in one
@@ -131,6 +137,16 @@ static PartSlot part_slot(long tokens, int D, int nseq) {
 }
 static size_t partial_bytes(long tokens, int D, int nseq, int layers) { return part_slot(tokens, D, nseq).bytes * (size_t)(layers > 0 ? layers : 0); }
 
+// the four weight gradients of a layer as one grouped launch: (c_proj, c_fc, out_proj, in_proj)
+static void group_dims(int D, int (&Np)[4], int (&Kp)[4]) {
+  Np[0] = D; Kp[0] = 4 * D; Np[1] = 4 * D; Kp[1] = D; Np[2] = D; Kp[2] = D; Np[3] = 3 * D; Kp[3] = D;
+}
+static size_t group_ws_bytes(long tokens, int D) {
+  int Np[4], Kp[4];
+  group_dims(D, Np, Kp);
+  return hmmc_gemm_f16_wgrad_group_workspace(Np, Kp, 4, (int)tokens);
+}
+
 static size_t general_bytes(long tokens, int D, int fp32) {
   size_t w = hmmc_layernorm_bwd_workspace((int)tokens, D);
   size_t c = hmmc_colsum_workspace((int)tokens, 4 * D);
@@ -144,13 +160,17 @@ static size_t general_bytes(long tokens, int D, int fp32) {
     if (g3 > g) g = g3;
     if (g4 > g) g = g4;
     if (g > w) w = g;
+    size_t grp = group_ws_bytes(tokens, D);          // the grouped launch takes this region when there is no second stream
+    if (grp > w) w = grp;
   }
   return al(w);
 }
 
 static size_t wgrad_ws_bytes(long tokens, int D, int fp32) {
   if (fp32) return 0;
+  const size_t grp = group_ws_bytes(tokens, D);
   size_t g = hmmc_gemm_f16_workspace(3 * D, D, (int)tokens);
+  if (grp > g) g = grp;
   size_t g2 = hmmc_gemm_f16_workspace(4 * D, D, (int)tokens);
   size_t g3 = hmmc_gemm_f16_workspace(D, 4 * D, (int)tokens);
   size_t g4 = hmmc_gemm_f16_workspace(D, D, (int)tokens);
@@ -222,15 +242,17 @@ extern "C" int hmmc_tower_fwd(const void* x, void* y, const void* const* params,
 // dx = d tower / d x (dy given), grads[nlayers*12] written.  x0 is the tower input given to hmmc_tower_fwd.
 namespace {
 // Events between the main and the weight-gradient stream ("operand ready" and back, "operand no longer read"): one set per
-// (main stream, weight-gradient stream) pair, created on the pair's FIRST hmmc_tower_bwd call and kept for the life of the
+// (main stream, weight-gradient stream) pair (seven: operand ready, four "operand no longer read", two for the grouped launches
+// of even / odd layers), created on the pair's FIRST hmmc_tower_bwd call and kept for the life of the
 // process (hipEventCreate is the only allocation the library ever makes besides that of hmmc_gemm_profile_start; a
 // recorded event may be recorded again - a wait already enqueued keeps the record it was enqueued against).
 struct WgradSync {
-  hipEvent_t ready = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ready = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr}, gdone[2] = {nullptr, nullptr};
   bool ok = false;
   WgradSync() {
     ok = hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < 4; ++k) ok = ok && hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 2; ++k) ok = ok && hipEventCreateWithFlags(&gdone[k], hipEventDisableTiming) == hipSuccess;
   }
 };
 std::mutex g_sync_mu;
@@ -258,13 +280,20 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
   const long T = (long)nseq * L;
   const size_t slab = hmmc_tower_act_bytes(T, D, nseq, L, heads, fp32);
   char* sp = (char*)scratch;
-  void* dh = sp; sp += al((size_t)T * 4 * D * es);
-  void* dqkv = sp; sp += al((size_t)T * 3 * D * es);
+  void* dh_set[2]; void* dqkv_set[2]; void* dx1_set[2];
+  for (int k = 0; k < (f32 ? 1 : 2); ++k) {
+    dh_set[k] = sp; sp += al((size_t)T * 4 * D * es);
+    dqkv_set[k] = sp; sp += al((size_t)T * 3 * D * es);
+    dx1_set[k] = sp; sp += al((size_t)T * D * es);
+  }
+  if (f32) { dh_set[1] = dh_set[0]; dqkv_set[1] = dqkv_set[0]; dx1_set[1] = dx1_set[0]; }
   void* dln = sp; sp += al((size_t)T * D * es);
-  void* dx1 = sp; sp += al((size_t)T * D * es);
   void* ping[2];
   ping[0] = sp; sp += al((size_t)T * D * es);
   ping[1] = sp;
+  // grouped weight gradients (fp16 tower, shapes the 256x256 tile takes): one launch per layer once the layer's last
+  // gradient operand (dqkv) exists, on the weight-gradient stream; gdone[parity] orders the reuse of the operand set
+  const bool grouped = !f32 && group_ws_bytes(T, D) > 0;
   // workspace = [general][partials]; the fp16 tower takes three of its four bias gradients from the kernels that
   // produce the tensors (LayerNorm backward: out_proj / c_proj; QuickGELU' dgrad epilogue: c_fc; attention backward:
   // in_proj) instead of re-reading them.  Only the c_proj bias of the LAST layer still needs its own pass over dy.
@@ -294,6 +323,7 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
   WgradSync* const syncp = two ? wgrad_sync_for(s, sw) : nullptr;
   if (two && !syncp->ok) return HMMC_ERR_LAUNCH;
   bool done_set[4] = {false, false, false, false};
+  bool gdone_set[2] = {false, false};
   // weight gradient k of a layer (0: c_proj <- g_in, 1: c_fc <- dh, 2: out_proj <- dx1, 3: in_proj <- dqkv)
   auto side_wgrad = [&](int k, const void* dyk, const void* xk, void* dW, int Np, int Kp, int rows = 0, int ldy = 0,
                         int ldx = 0) -> int {
@@ -328,6 +358,16 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
     float* const p_fc = (float*)(sl + slot.fc);
     float* const p_attn = (float*)(sl + slot.attn);
     const size_t fc_bytes = slot.attn - slot.fc, attn_bytes = slot.bytes - slot.attn;
+    // this layer's set of transient gradients; a set is written again two layers on, after the grouped launch that read it
+    const int par = i & 1;
+    void* const dh = dh_set[par];
+    void* const dqkv = dqkv_set[par];
+    void* const dx1 = dx1_set[par];
+    const bool group_layer = grouped && !(lead_only && i + 1 == nlayers);
+    if (two && gdone_set[par]) {
+      if (hipStreamWaitEvent(s, syncp->gdone[par], 0) != hipSuccess) return HMMC_ERR_LAUNCH;
+      gdone_set[par] = false;
+    }
     if (lead_only && i + 1 == nlayers) {
       // Last block, leading rows only (see hmmc_tower_fwd): g_in = dy and x1 / att are addressed at stride L*D, dh / dln / ln2 /
       // g / h are compact [nseq, .].  dx1 and the attention-output gradient are full [T, D] buffers that the attention and
@@ -347,7 +387,7 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
       CK(hmmc_gemm_f16(dx1, P[4], dln, nseq, D, D, ldl, D, ldl, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, s));
     } else {
     // MLP: x2 = x1 + c_proj(QuickGELU(c_fc(ln2)))
-    CK(side_wgrad(0, g_in, a.g, G[10], D, 4 * D));
+    if (!group_layer) CK(side_wgrad(0, g_in, a.g, G[10], D, 4 * D));
     CK(before_overwrite(1));
     if (f32) {
       CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_DGELU, s));
@@ -357,13 +397,13 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
       CK(dgrad(f32, g_in, P[10], dh, (int)T, D, 4 * D, a.h, EPI_MULAUX, s, p_fc, fc_bytes));
       defer(p_fc, rows, 4 * D, 4 * D, G[9], dt);
     }
-    CK(side_wgrad(1, dh, a.ln2, G[8], 4 * D, D));
+    if (!group_layer) CK(side_wgrad(1, dh, a.ln2, G[8], 4 * D, D));
     CK(dgrad(f32, dh, P[8], dln, (int)T, 4 * D, D, nullptr, 0, s));
     CK(before_overwrite(2));
     CK(ln_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], G[5], (int)T, D,
               p_ln2));                                                         // G[5]: out_proj bias = colsum(dx1)
     // attention: x1 = x + out_proj(attn(in_proj(ln1)))
-    CK(side_wgrad(2, dx1, a.att, G[4], D, D));
+    if (!group_layer) CK(side_wgrad(2, dx1, a.att, G[4], D, D));
     CK(dgrad(f32, dx1, P[4], dln, (int)T, D, D, nullptr, 0, s));                 // datt (reuses dln)
     }
     CK(before_overwrite(3));
@@ -375,11 +415,30 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
       defer(p_attn, nseq, 3 * D, 3 * D, G[3], dt);
       (void)attn_bytes;
     }
-    CK(side_wgrad(3, dqkv, a.ln1, G[2], 3 * D, D));
+    if (group_layer) {
+      // all four weight gradients of the layer, now that the last operand (dqkv) exists
+      const void* gy[4] = {g_in, dh, dx1, dqkv};
+      const void* gx[4] = {a.g, a.ln2, a.att, a.ln1};
+      void* gw[4] = {G[10], G[8], G[4], G[2]};
+      int Np[4], Kp[4];
+      group_dims(D, Np, Kp);
+      if (two && (hipEventRecord(syncp->ready, s) != hipSuccess || hipStreamWaitEvent(sw, syncp->ready, 0) != hipSuccess)) return HMMC_ERR_LAUNCH;
+      CK(hmmc_gemm_f16_wgrad_group(gy, gx, gw, Np, Kp, 4, (int)T, two ? wws : workspace, two ? wws_bytes : gen, sw));
+      if (two) {
+        if (hipEventRecord(syncp->gdone[par], sw) != hipSuccess) return HMMC_ERR_LAUNCH;
+        gdone_set[par] = true;
+      }
+    } else {
+      CK(side_wgrad(3, dqkv, a.ln1, G[2], 3 * D, D));
+    }
     CK(dgrad(f32, dqkv, P[2], dln, (int)T, 3 * D, D, nullptr, 0, s));
     // the c_proj bias gradient of the layer below is the column sum of the dx this call writes (into the buffer weight
     // gradient 0 of the layer above read as its g_in)
     CK(before_overwrite(0));
+    if (two && gdone_set[par ^ 1]) {                // g_out is the g_in the grouped launch of the layer above reads
+      if (hipStreamWaitEvent(s, syncp->gdone[par ^ 1], 0) != hipSuccess) return HMMC_ERR_LAUNCH;
+      gdone_set[par ^ 1] = false;
+    }
     CK(ln_bwd(dln, xin, (const float*)P[0], a.m1, a.r1, dx1, g_out, (float*)G[0], (float*)G[1],
               i > 0 ? grads[(size_t)(i - 1) * 12 + 11] : nullptr, (int)T, D, p_ln1));
     g_in = g_out;

@@ -117,6 +117,29 @@ def gemm_f16(a, b, M, N, K, a_kmajor=True, b_kmajor=True, bias=None, resid=None,
     return (c, aux_out) if want_aux else c
 
 
+def wgrad_group(dys, xs):
+    """[dY_j^T X_j for j] (fp16, up to four problems over the same token count) in one grouped launch; None when the shapes
+    should take one gemm_f16 call each (hmmc_gemm_f16_wgrad_group_workspace == 0)."""
+    import ctypes
+    n = len(dys)
+    T = dys[0].shape[0]
+    for dy, x in zip(dys, xs):
+        _chk(dy, torch.float16, "dy")
+        _chk(x, torch.float16, "x")
+        assert dy.shape[0] == T and x.shape[0] == T
+    Np = (ctypes.c_int * n)(*[dy.shape[1] for dy in dys])
+    Kp = (ctypes.c_int * n)(*[x.shape[1] for x in xs])
+    wsb = query("hmmc_gemm_f16_wgrad_group_workspace", Np, Kp, n, T)
+    if wsb == 0:
+        return None
+    ws = workspace(wsb, dys[0].device, "gemm_group")
+    outs = [torch.empty((dy.shape[1], x.shape[1]), dtype=torch.float16, device=dy.device) for dy, x in zip(dys, xs)]
+    P = ctypes.c_void_p * n
+    call("hmmc_gemm_f16_wgrad_group", P(*[t.data_ptr() for t in dys]), P(*[t.data_ptr() for t in xs]), P(*[t.data_ptr() for t in outs]),
+         Np, Kp, n, T, ptr(ws), wsb)
+    return outs
+
+
 def layernorm_fwd(x, gamma, beta, eps, rows=None, row_index=None, in_stride=None):
     """x: [..., D] fp16 or fp32.  Optional row gather: output row r reads x_flat[row_index[r]]."""
     D = x.shape[-1]

@@ -61,6 +61,15 @@ size_t hmmc_gemm_f16_colsum_rows(int M, int N, int K);
  * returns, per operand layout (0 forward, 1 dgrad, 2 wgrad), the summed 2MNK flops, algorithmic operand bytes, seconds and launch counts. */
 int hmmc_gemm_profile_start(void);
 int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seconds, long* launches);
+/* The weight gradients of one layer as ONE launch: dW_j[Np_j, Kp_j] = dY_j[T, Np_j]^T X_j[T, Kp_j], j < nprob <= 4, all over the
+ * same T tokens (F.linear's weight gradients of in_proj / out_proj / c_fc / c_proj, modules/module_clip.py:231-257).  Work
+ * items of all problems share one persistent grid and one K split (chosen so that their tiles together fill the chip), fp32
+ * partial slabs in `workspace`, one reduce.  dY / X / dW / Np / Kp: HOST arrays of nprob device pointers / sizes.
+ * hmmc_gemm_f16_wgrad_group_workspace returns the workspace bytes, or 0 when the shapes should take one hmmc_gemm_f16 call per
+ * gradient instead (dimensions that are not multiples of 256, fewer than 2048 tokens, operands of 2 GiB and more). */
+size_t hmmc_gemm_f16_wgrad_group_workspace(const int* Np, const int* Kp, int nprob, int T);
+int hmmc_gemm_f16_wgrad_group(const void* const* dY, const void* const* X, void* const* dW, const int* Np, const int* Kp,
+                              int nprob, int T, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
 /* Leave `cus` (0..128, default 0) compute units out of every later hmmc_gemm_f16 grid.  The host sets this once when
  * gradients are all-reduced while the backward pass runs (DistributedDataParallel at main_task_retrieval.py:207, main_pretrain.py:204), so that
  * RCCL's workgroups find free CUs instead of waiting for a persistent GEMM grid to drain.  Process-wide. */

@@ -79,6 +79,27 @@ def test_gemm_big_tile_exact_integers(layout, M, N, K):
     assert torch.equal(c.float(), ref), f"max diff {(c.float()-ref).abs().max()}"
 
 
+@pytest.mark.parametrize("T,D", [(2048, 256), (4480, 512), (19200, 768), (40000, 768)])
+def test_gemm_grouped_weight_gradients_exact_integers(T, D):
+    """The four weight gradients of a layer in one grouped launch (hmmc_gemm_f16_wgrad_group): bit-exact on integer data
+    against fp32 torch for every problem, with token counts that are not multiples of the K tile or of the split, and the
+    same results as one hmmc_gemm_f16 call per gradient."""
+    g = torch.Generator().manual_seed(T + D)
+    dims = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)]                      # c_proj, c_fc, out_proj, in_proj
+    dys = [torch.randint(-2, 3, (T, n), generator=g).half().to(DEV) for n, _ in dims]
+    xs = [torch.randint(-2, 3, (T, k), generator=g).half().to(DEV) for _, k in dims]
+    outs = ops.wgrad_group(dys, xs)
+    assert outs is not None
+    for dy, x, o in zip(dys, xs, outs):
+        ref = dy.float().t() @ x.float()
+        assert torch.equal(o.float(), ref.half().float()), float((o.float() - ref).abs().max())
+        single = ops.gemm_f16(dy, x, dy.shape[1], x.shape[1], T, a_kmajor=False, b_kmajor=False)
+        assert torch.equal(o, single)
+    assert ops.wgrad_group([d[:1000] for d in dys], [x[:1000] for x in xs]) is None           # too few tokens: per-gradient calls
+    small = ops.wgrad_group([torch.zeros(4096, 128, dtype=torch.float16, device=DEV)], [torch.zeros(4096, 384, dtype=torch.float16, device=DEV)])
+    assert small is None                                                                       # not 256-tile shaped
+
+
 @pytest.mark.parametrize("layout", ["kk", "km", "mm"])
 def test_gemm_operands_beyond_2gib(layout):
     """An operand of 2 GiB or more (SURVEY config 5 on one GPU: 605 184 tokens x 3072 fp16 = 3.7 GB) exceeds what one launch's
