@@ -118,7 +118,7 @@ def eval_leg(args, dev):
         import oracle.hmmc_oracle as O
         n_s = min(nq, 1500)
         q, v, u = torch.cat(qs)[:n_s].cpu(), torch.cat(vs).cpu(), torch.cat(us).cpu()
-        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))     # as cpu_baseline()
+        torch.set_num_threads(_usable_cores())     # as cpu_baseline()
         ls = float(model.text_encoder.logit_scale)
 
         def cpu_scores(qq):
@@ -163,6 +163,29 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown CPU"
+
+
+def _usable_cores():
+    """Host cores this process can really use: the affinity mask capped by the cgroup's CPU quota.  The GPU boxes pin nothing
+    (256 CPUs visible) but grant a quota of 16 cores (cpu.max = 1600000 100000): 64 threads on that quota ran the GEMM-bound
+    oracle step SLOWER than 16 (1 135 vs 1 551 GFLOP/s on a 4096^3 matmul) - round 2's "64 threads" baseline was throttled."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:                                                           # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                pr = int(f.read())
+            if q > 0:
+                n = min(n, max(1, -(-q // pr)))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 64))
 
 
 def _cpu_steps(B, frames, length, threads, warmups, min_steps, seconds, max_steps=5):
@@ -218,7 +241,7 @@ def cpu_baseline(frames, length, batch=16, warmups=2, min_steps=2, seconds=40.0)
     steps, CPU model and core count reported; the step is split into forward / backward / clip + BertAdam, and the same
     step is also timed on 8 threads - BASELINE.md section 4's cross-check against the reference itself, which ran 1.77
     pairs/s (fp32) on the 8 cores of the survey container."""
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))     # the cores this process may actually use
+    cores = _usable_cores()
     B = batch
     dt, n, split = _cpu_steps(B, frames, length, cores, warmups, min_steps, seconds)
     out = {"value": round(B / dt, 4), "unit": "video-text pairs/s", "cores": cores, "kind": "port",
