@@ -107,3 +107,34 @@ for case in range(ncases // 3):
 torch.cuda.synchronize()
 ops.raise_on_device_errors()
 print("done, mismatches", bad)
+
+# ---- round 3: fp32 attention of the fp32 regime (1..256 tokens, both kernels) and grouped weight gradients
+for case in range(max(ncases // 5, 20)):
+    nseq, L, H, causal = rng.randint(1, 5), rng.randint(1, 256), rng.choice([1, 2, 8, 12]), rng.random() < 0.4
+    D = 64 * H
+    qkv = torch.randn(nseq * L, 3 * D, device=DEV)
+    dout = torch.randn(nseq * L, D, device=DEV)
+    out, probs = ops.attention_f32_fwd(qkv, nseq, L, H, causal)
+    qr = qkv.clone().requires_grad_()
+    q, k, v = qr.view(nseq, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=DEV).triu_(1)
+    oref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(nseq * L, D)
+    oref.backward(dout)
+    dqkv = ops.attention_f32_bwd(qkv, probs, dout, nseq, L, H)
+    e1 = float((out - oref).abs().max()); e2 = float((dqkv - qr.grad).abs().max())
+    report(e1 < 2e-5 and e2 < 2e-4, ("attention_f32", nseq, L, H, causal, e1, e2))
+print("fp32 attention done, mismatches", bad, flush=True)
+for case in range(max(ncases // 10, 10)):
+    T = rng.choice([2048, 2056, 5000, 12345 - 12345 % 8, 30000])
+    D = rng.choice([256, 512, 768])
+    n = rng.randint(1, 4)
+    dims = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)][:n]
+    dys = [ints(T, a) for a, _ in dims]
+    xs = [ints(T, b) for _, b in dims]
+    outs = ops.wgrad_group(dys, xs)
+    report(outs is not None and all(torch.equal(o.float(), (dy.float().t() @ x.float()).half().float()) for dy, x, o in zip(dys, xs, outs)),
+           ("wgrad_group", T, D, n))
+print("grouped weight gradients done, mismatches", bad, flush=True)
+print("TOTAL mismatches", bad)
