@@ -686,3 +686,59 @@ def test_clip_grad_norm_follows_the_gradients_it_is_given():
         coef = min(1.0, 1.0 / (float(total) + 1e-6))
         for p, r in zip(ps, ref):
             close(p.grad, r * coef, 1e-6, 2e-3 if dtype == torch.float16 else 1e-5, "clipped gradient")
+
+
+@pytest.mark.parametrize("width,heads,L,nseq,causal", [(256, 4, 50, 48, False), (512, 8, 32, 80, True)])
+def test_tower_grouped_weight_gradients_streams_and_oracle(width, heads, L, nseq, causal):
+    """A tower backward with enough tokens (>= 2048) and 256-multiple widths takes the grouped weight-gradient launch
+    (hmmc_gemm_f16_wgrad_group: one launch per layer on the weight-gradient stream, transient gradients alternating between
+    two sets, events per layer parity).  Every gradient must be bit-identical with the second stream on and off and from run
+    to run - a missing event between the chain and the grouped launch would show here - and agree with the fp32 oracle of
+    the same blocks (modules/module_clip.py:231-268)."""
+    from hmmc_amd import module_clip
+    import hmmc_amd.functional as Fn2
+    T = nseq * L
+    assert T >= 2048 and width % 256 == 0
+    torch.manual_seed(11)
+    layers = 3
+    tw = module_clip.Transformer(width, layers, heads, attn_mask="causal" if causal else None)
+    for prm in tw.parameters():
+        torch.nn.init.normal_(prm, std=0.04 if prm.dim() > 1 else 0.1)
+    for blk in tw.resblocks:
+        blk.ln_1.weight.data.add_(1.0)
+        blk.ln_2.weight.data.add_(1.0)
+    module_clip.convert_weights(tw)
+    sd = {f"t.{k}": v.detach().float().clone().requires_grad_() for k, v in tw.state_dict().items()}
+    tw = tw.to(DEV)
+    x0 = (torch.randn(T, width) * 0.5).half()
+    wsel = torch.randn(T, width) * 0.1
+
+    def run(wgrad_stream):
+        Fn2._WGRAD_STREAM = wgrad_stream
+        for prm in tw.parameters():
+            prm.grad = None
+        x = x0.to(DEV).requires_grad_()
+        y = tw(x, nseq, L)
+        (y.float() * wsel.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in tw.named_parameters()}
+
+    saved = Fn2._WGRAD_STREAM
+    try:
+        y1, dx1, g1 = run(True)
+        y2, dx2, g2 = run(True)
+        y3, dx3, g3 = run(False)
+    finally:
+        Fn2._WGRAD_STREAM = saved
+    assert torch.equal(y1, y2) and torch.equal(y1, y3) and torch.equal(dx1, dx2) and torch.equal(dx1, dx3)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), f"run-to-run difference in {n}"
+        assert torch.equal(g1[n], g3[n]), f"weight-gradient stream on / off difference in {n}"
+    xo = x0.float().view(nseq, L, width).clone().requires_grad_()
+    yo = O.transformer(xo, sd, "t", heads, O.causal_mask(L) if causal else None, torch.float32)
+    (yo * wsel.view(nseq, L, width)).sum().backward()
+    assert relerr(y1.cpu(), yo.detach().view(T, width)) < 5e-3
+    assert relerr(dx1.cpu(), xo.grad.view(T, width)) < 2e-2
+    for n in g1:
+        e = relerr(g1[n].cpu(), sd["t." + n].grad)
+        assert e < 2e-2, (n, e)
