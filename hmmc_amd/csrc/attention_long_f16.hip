@@ -159,217 +159,303 @@ __global__ __launch_bounds__(64 * NW, fwd_min_waves(KTL, NW)) void attn_long_fwd
   }
 }
 
-// Backward: one workgroup per (sequence, head) again, NW waves.  K, V, Q and dO of the head (4 x 32 KiB at 197 tokens) go into
-// LDS once, lane-ordered; delta[q] = <dO[q], O[q]> (the row sum of P o dP, from the saved output) is formed from the same
-// registers on the way in; the log-sum-exp is kept pre-multiplied by log2(e).
-//  phase 1, a wave per 16-query tile: keys on the lane's rows (S^T = K Q^T, dP^T = V dO^T, K / V fragments by ds_read_b128),
-//    dS of the WHOLE key range in registers (KTL x 8 bytes per lane), dQ^T = K^T dS^T with K^T by ds_read_b64_tr_b16;
-//  phase 2, a wave per 16-key tile: queries on the lane's rows, two query tiles at a time (one K = 32 MFMA step):
-//    dV^T += dO^T P and dK^T += Q^T dS with dO^T / Q^T by transposed reads - 32 accumulator registers per wave.
-// Nothing is fetched from global memory between the first MFMA and the last, every operand byte is read once per head (the
-// previous three one-wave-per-64-rows kernels read K, V, Q, dO and O about 4 + 4 + 4 times), and S / dP are formed twice
-// instead of three times.
+// Backward: persistent workgroups of NW = 8 waves, one per CU (the four operand images of a head fill the LDS), each walking
+// (sequence, head) pairs.  Per head two phases, and every full-size operand image arrives by LDS-DMA (buffer_load ... lds: no
+// registers, asynchronous) UNDER the phase before the one that needs it:
+//   phase 1 (dQ), a wave per 16-query tile: K and V images resident (they landed during the previous head's phase 2); the tile's
+//     own Q / dO / O rows come from global memory through the wave's staging tile, one tile ahead (delta[q] = <dO[q], O[q]> and the
+//     log-sum-exp go to LDS for phase 2); S^T = K Q^T and dP^T = V dO^T by ds_read_b128 fragments, dS of the whole key range in
+//     registers, dQ^T = K^T dS^T by transposed reads.  Meanwhile the Q and dO images of THIS head are in flight.
+//   phase 2 (dK, dV), a wave per 16-key tile, two query tiles at a time: Q and dO images resident; the wave takes the K / V
+//     fragments of its own key tiles into registers first, and after a barrier the K and V images are dead: the NEXT head's K
+//     and V are requested into them and land while dV^T += dO^T P and dK^T += Q^T dS run.
+// The images are unpadded [rows][64] with the chunk index XORed by swz_tr(row) on the SOURCE side of the DMA (the LDS side of a
+// DMA is lane-linear); rows past L belong to the next sequence (or read as zero past the tensor: the descriptor ends there) and
+// only ever meet probabilities that are exactly zero.  Round 2's kernel loaded all five operands synchronously in front of
+// the phases: 35 % of its time (skip-phase builds: 476 us = 114 phase 1 + 195 phase 2 + 167 load / store / barriers).
 // 8 halves op[row][8 chunk .. +7] of an image swizzled with swz_tr (conflict-free for ds_read_b128 as well: rows c and c + 8 of a
 // 16-lane group never share a chunk because the two groups of g differ in bit 0 of the chunk)
 __device__ __forceinline__ h8 frag_t(const half_t* tile, int row, int chunk) {
   return *reinterpret_cast<const h8*>(tile + row * DH + ((chunk ^ swz_tr(row)) << 3));
 }
 
+template <int ROWS, int NW>
+__device__ __forceinline__ void dma_image(__amdgpu_buffer_rsrc_t rsrc, half_t* image, unsigned col_bytes, unsigned ld_bytes,
+                                          int wid, int lane) {
+  for (int rb = wid; rb < ROWS / 8; rb += NW) {                  // 1 KiB per wave-instruction: image rows 8 rb .. 8 rb + 7
+    const int row = rb * 8 + (lane >> 3);
+    const int lc = (lane & 7) ^ swz_tr(row);
+    const unsigned voff = (unsigned)row * ld_bytes + col_bytes + (unsigned)lc * 16u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(reinterpret_cast<char*>(image) + rb * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
 template <int KTL, int NW, bool CAUSAL>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(AttnArgs p) {
-  constexpr int ROWS = 16 * KTL, NT = 64 * NW, RPP = NT / 8;              // rows per cooperative pass
+  constexpr int ROWS = 16 * KTL;
+  static_assert(NW * 2 >= KTL, "a wave holds the K / V fragments of at most two key tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane0 = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int D = p.H * DH, L = p.L;
   const long ld = 3L * D;
-  const half_t* q = p.qkv + (long)n * L * ld + h * DH;
-  const half_t* k = q + D;
-  const half_t* v = q + 2 * D;
-  const half_t* dO = p.dout + (long)n * L * D + h * DH;
-  const half_t* o = p.out + (long)n * L * D + h * DH;
-  half_t* dq = p.dqkv + (long)n * L * ld + h * DH;
-  half_t* dk = dq + D;
-  half_t* dv = dq + 2 * D;
   half_t* ktile = reinterpret_cast<half_t*>(smem);
-  half_t* vtile = ktile + ROWS * DH;               // four unpadded images, chunk index XORed with swz_tr(row): every one of
-  half_t* qtile = vtile + ROWS * DH;               // them is read both as row fragments and transposed (both conflict-free)
+  half_t* vtile = ktile + ROWS * DH;
+  half_t* qtile = vtile + ROWS * DH;
   half_t* dtile = qtile + ROWS * DH;
   half_t* scr = dtile + ROWS * DH + wid * (16 * LDS_STRIDE);
   float* lse_s = reinterpret_cast<float*>(dtile + ROWS * DH + NW * 16 * LDS_STRIDE);
   float* del_s = lse_s + ROWS;
   float* red = del_s + ROWS;                     // [3][NW][64]: every wave's column sums of its dQ / dK / dV tiles
   const bool want_dbias = p.dbias != nullptr;
-  const int g = lane >> 4, c = lane & 15;
-  const float* lse_g = p.lse + ((long)n * p.H + h) * L;
-  // ---- operands -> LDS (thread -> row (tid >> 3) + RPP i, bytes 16 (tid & 7) .. +15; rows past L zero) and delta
-#pragma unroll
-  for (int i = 0; i < (ROWS + RPP - 1) / RPP; ++i) {
-    const int row = (tid >> 3) + RPP * i;
-    const int rc = min(row, L - 1);
-    const int ch = 8 * (tid & 7);
-    const u4v z = {0u, 0u, 0u, 0u};
-    const bool in = row < L;
-    const u4v rk = *reinterpret_cast<const u4v*>(k + (long)rc * ld + ch);
-    const u4v rv = *reinterpret_cast<const u4v*>(v + (long)rc * ld + ch);
-    const u4v rq = *reinterpret_cast<const u4v*>(q + (long)rc * ld + ch);
-    const u4v rd = *reinterpret_cast<const u4v*>(dO + (long)rc * D + ch);
-    const u4v ro = *reinterpret_cast<const u4v*>(o + (long)rc * D + ch);
-    if (ROWS % RPP == 0 || row < ROWS) {
-      const int so = row * DH + (((tid & 7) ^ swz_tr(row)) << 3);
-      *reinterpret_cast<u4v*>(ktile + so) = in ? rk : z;
-      *reinterpret_cast<u4v*>(vtile + so) = in ? rv : z;
-      *reinterpret_cast<u4v*>(qtile + so) = in ? rq : z;
-      *reinterpret_cast<u4v*>(dtile + so) = in ? rd : z;
-    }
-    const h8 hd = __builtin_bit_cast(h8, rd), ho = __builtin_bit_cast(h8, ro);
-    float dl = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dl += (float)hd[j] * (float)ho[j];
-    dl += __shfl_xor(dl, 1, 64);                 // the 8 threads of a row are consecutive lanes
-    dl += __shfl_xor(dl, 2, 64);
-    dl += __shfl_xor(dl, 4, 64);
-    if ((tid & 7) == 0 && (ROWS % RPP == 0 || row < ROWS)) {
-      del_s[row] = in ? dl : 0.f;
-      lse_s[row] = in ? LOG2E * lse_g[rc] : INFINITY;    // +inf past L: those queries' probabilities vanish
-    }
-  }
-  __syncthreads();
   const int nt = (L + 15) / 16;                  // 16-row tiles that hold a real token
   constexpr float C1 = 0.125f * LOG2E;
-  // ---- phase 1: dQ
-  f4 csum[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) csum[dt] = f4{0.f, 0.f, 0.f, 0.f};
-  for (int qt = wid; qt < nt; qt += NW) {
-    const int qi = qt * 16 + c;
-    h8 qf[2], df[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      qf[ks] = frag_t(qtile, qt * 16 + c, ks * 4 + g);
-      df[ks] = frag_t(dtile, qt * 16 + c, ks * 4 + g);
-    }
-    const float lq = lse_s[qi], dlq = del_s[qi];
-    h4 ds16[KTL];
-#pragma unroll
-    for (int k0 = 0; k0 < KTL; k0 += 2) {          // two key tiles per round: their 8 fragments are requested together
-      h8 kf[2][2], vf[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = (k0 + i) * 16 + c;
-        kf[i][0] = frag_t(ktile, row, g); kf[i][1] = frag_t(ktile, row, 4 + g);
-        vf[i][0] = frag_t(vtile, row, g); vf[i][1] = frag_t(vtile, row, 4 + g);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int kt = k0 + i;
-        f4 z = {0.f, 0.f, 0.f, 0.f};
-        f4 sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][0], qf[0], z, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][1], qf[1], sc, 0, 0, 0);
-        f4 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[i][0], df[0], z, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[i][1], df[1], dp, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], C1, -lq));
-          if (CAUSAL) pv = (key < L && key <= qi) ? pv : 0.f;
-          else if (kt >= KTL - 2) pv = key < L ? pv : 0.f;
-          ds16[kt][r] = (half_t)(pv * (dp[r] - dlq));            // the 1/8 of dS is applied to the 16 results below
-        }
-      }
-    }
-    f4 acc[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KTL / 2; ++ks)
-        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag_swz(ktile, ks * 32, ks * 32 + 16, dt * 16, lane),
-                                                         cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[dt], 0, 0, 0);
-      acc[dt] *= 0.125f;
-    }
-    store_rows(dq, ld, acc, qt * 16, L, scr, lane);
-    if (want_dbias) add_rounded(csum, acc);        // queries past L are exact zeros (their dS is)
+  const int total = p.nseq * p.H;
+  const unsigned ldb = (unsigned)(ld * 2), ldo = (unsigned)(D * 2);
+  // descriptors start at the sequence's first row and end with the tensor (at most 1 GiB ahead: a head touches ROWS rows)
+  auto rsrc_qkv = [&](int n) {
+    const long left = (long)(p.nseq - n) * L * ld * 2;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(p.qkv + (long)n * L * ld), 0, (int)(left < (1l << 30) ? left : (1l << 30)), 0x00020000);
+  };
+  auto rsrc_dout = [&](int n) {
+    const long left = (long)(p.nseq - n) * L * D * 2;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(p.dout + (long)n * L * D), 0, (int)(left < (1l << 30) ? left : (1l << 30)), 0x00020000);
+  };
+  {                                              // the first head's K and V
+    const int n = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const __amdgpu_buffer_rsrc_t r = rsrc_qkv(n);
+    dma_image<ROWS, NW>(r, ktile, (unsigned)((D + h * DH) * 2), ldb, wid, lane0);
+    dma_image<ROWS, NW>(r, vtile, (unsigned)((2 * D + h * DH) * 2), ldb, wid, lane0);
   }
-  if (want_dbias) store_colsum(red + wid * 64, csum, lane);
-  // ---- phase 2: dV and dK
-  f4 csk[4];
+  for (int head = blockIdx.x; head < total; head += gridDim.x) {
+    // the lane index is made opaque per head: every LDS address below is a function of it, and with a loop-invariant lane
+    // index the compiler hoists ~150 address registers out of this loop and spills them
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, c = lane & 15;
+    const int n = head / p.H, h = head % p.H;
+    const half_t* q = p.qkv + (long)n * L * ld + h * DH;
+    const half_t* dO = p.dout + (long)n * L * D + h * DH;
+    const half_t* o = p.out + (long)n * L * D + h * DH;
+    half_t* dq = p.dqkv + (long)n * L * ld + h * DH;
+    half_t* dk = dq + D;
+    half_t* dv = dq + 2 * D;
+    const float* lse_g = p.lse + ((long)n * p.H + h) * L;
+    // a query tile's Q / dO / O rows, lane-ordered (row (lane >> 3) + 8 t, bytes 16 (lane & 7) .. +15), and its log-sum-exp
+    u4v rq[2], rd[2], ro[2];
+    float rl;
+    auto load_tile = [&](int qt) {
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) { csum[dt] = f4{0.f, 0.f, 0.f, 0.f}; csk[dt] = f4{0.f, 0.f, 0.f, 0.f}; }
-  for (int kt = wid; kt < nt; kt += NW) {
-    const int key = kt * 16 + c;
-    const bool key_ok = key < L;
-    h8 kf[2], vf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      kf[ks] = frag_t(ktile, kt * 16 + c, ks * 4 + g);
-      vf[ks] = frag_t(vtile, kt * 16 + c, ks * 4 + g);
-    }
-    f4 av[4], ak[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { av[dt] = f4{0.f, 0.f, 0.f, 0.f}; ak[dt] = f4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int qp = 0; qp < KTL / 2; ++qp) {
-      h4 p16[2], ds16[2];
-      h8 qf[2][2], df[2][2];
-      f4 lr[2], dl[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {                // both query tiles of the pair: fragments, lse and delta requested together
-        const int qt = 2 * qp + e;
-        qf[e][0] = frag_t(qtile, qt * 16 + c, g); qf[e][1] = frag_t(qtile, qt * 16 + c, 4 + g);
-        df[e][0] = frag_t(dtile, qt * 16 + c, g); df[e][1] = frag_t(dtile, qt * 16 + c, 4 + g);
-        lr[e] = *reinterpret_cast<const f4*>(lse_s + qt * 16 + 4 * g);
-        dl[e] = *reinterpret_cast<const f4*>(del_s + qt * 16 + 4 * g);
+      for (int t = 0; t < 2; ++t) {
+        const long row = min(qt * 16 + (lane >> 3) + 8 * t, L - 1);
+        rq[t] = *reinterpret_cast<const u4v*>(q + row * ld + 8 * (lane & 7));
+        rd[t] = *reinterpret_cast<const u4v*>(dO + row * D + 8 * (lane & 7));
+        ro[t] = *reinterpret_cast<const u4v*>(o + row * D + 8 * (lane & 7));
       }
-      h8 dT[4], qT[4];                             // dO^T / Q^T of the pair, used after the exponentials
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        dT[dt] = tr_frag_swz(dtile, qp * 32, qp * 32 + 16, dt * 16, lane);
-        qT[dt] = tr_frag_swz(qtile, qp * 32, qp * 32 + 16, dt * 16, lane);
-      }
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int qt = 2 * qp + e;
-        f4 z = {0.f, 0.f, 0.f, 0.f};
-        f4 sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[e][0], kf[0], z, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[e][1], kf[1], sc, 0, 0, 0);
-        f4 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[e][0], vf[0], z, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[e][1], vf[1], dp, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qi = qt * 16 + 4 * g + r;
-          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], C1, -lr[e][r]));   // 0 for queries past L (lse = +inf)
-          pv = (key_ok && (!CAUSAL || key <= qi)) ? pv : 0.f;
-          p16[e][r] = (half_t)pv;
-          ds16[e][r] = (half_t)(pv * (dp[r] - dl[e][r]));         // the 1/8 of dS is applied to dK below
-        }
-      }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dT[dt], cat4(p16[0], p16[1]), av[dt], 0, 0, 0);
-        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qT[dt], cat4(ds16[0], ds16[1]), ak[dt], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) ak[dt] *= 0.125f;
-    store_rows(dv, ld, av, kt * 16, L, scr, lane);
-    store_rows(dk, ld, ak, kt * 16, L, scr, lane);
-    if (want_dbias) { add_rounded(csum, av); add_rounded(csk, ak); }   // keys past L are exact zeros (P and dS are)
-  }
-  // in_proj bias-gradient partials of this (sequence, head): the waves' sums in wave order (fixed: bit-stable)
-  if (want_dbias) {
-    store_colsum(red + (1 * NW + wid) * 64, csk, lane);
-    store_colsum(red + (2 * NW + wid) * 64, csum, lane);
+      rl = lse_g[min(qt * 16 + c, L - 1)];
+    };
+    load_tile(min(wid, nt - 1));                 // requested BEFORE the DMAs below: the in-order vmcnt then does not make the
+                                                 // first tile wait for 56 KiB of images
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but 6 of those 7 loads: the K / V images of this head (older) have landed
     __syncthreads();
-    if (tid < 192) {
-      const int type = tid >> 6, d = tid & 63;
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) t += red[(type * NW + w) * 64 + d];
-      p.dbias[(long)n * 3 * D + type * D + h * DH + d] = t;
+    {                                            // this head's Q and dO images: needed in phase 2, in flight under phase 1
+      dma_image<ROWS, NW>(rsrc_qkv(n), qtile, (unsigned)(h * DH * 2), ldb, wid, lane);
+      dma_image<ROWS, NW>(rsrc_dout(n), dtile, (unsigned)(h * DH * 2), ldo, wid, lane);
     }
+    // ---- phase 1: dQ
+    f4 csum[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) csum[dt] = f4{0.f, 0.f, 0.f, 0.f};
+#ifndef HMMC_ATTN_PIN
+#define HMMC_ATTN_PIN 1
+#endif
+#ifndef HMMC_ATTN_SKIP
+#define HMMC_ATTN_SKIP 0          // timing / register experiments (scratch/): 1 skips phase 1, 2 skips phase 2 (wrong results)
+#endif
+    for (int qt = wid; qt < nt && HMMC_ATTN_SKIP != 1; qt += NW) {
+      const int q0 = qt * 16, qi = q0 + c;
+      const u4v z = {0u, 0u, 0u, 0u};
+      // delta and lse of the tile -> LDS (phase 2 reads them for every query), this wave's own values straight from registers
+      float dlv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const h8 hd = __builtin_bit_cast(h8, rd[t]), ho = __builtin_bit_cast(h8, ro[t]);
+        float dl = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += (float)hd[j] * (float)ho[j];
+        dl += __shfl_xor(dl, 1, 64);               // the 8 lanes of a row are consecutive
+        dl += __shfl_xor(dl, 2, 64);
+        dl += __shfl_xor(dl, 4, 64);
+        const int row = q0 + (lane >> 3) + 8 * t;
+        dlv[t] = row < L ? dl : 0.f;
+        if ((lane & 7) == 0) del_s[row] = dlv[t];
+      }
+      const float lq = qi < L ? LOG2E * rl : INFINITY;          // +inf past L: those queries' probabilities vanish
+      if (g == 0) lse_s[qi] = lq;
+      // rows -> staging tile -> fragments (rows past L as zeros), Q then dO through the same tile (a wave's LDS operations are in order)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        *reinterpret_cast<u4v*>(scr + ((lane >> 3) + 8 * t) * LDS_STRIDE + 8 * (lane & 7)) = q0 + (lane >> 3) + 8 * t < L ? rq[t] : z;
+      h8 qf[2], df[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const h8*>(scr + c * LDS_STRIDE + ks * 32 + 8 * g);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        *reinterpret_cast<u4v*>(scr + ((lane >> 3) + 8 * t) * LDS_STRIDE + 8 * (lane & 7)) = q0 + (lane >> 3) + 8 * t < L ? rd[t] : z;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) df[ks] = *reinterpret_cast<const h8*>(scr + c * LDS_STRIDE + ks * 32 + 8 * g);
+      const float dlq = del_s[qi];
+      h4 ds16[KTL];
+#pragma unroll
+      for (int k0 = 0; k0 < KTL; k0 += 2) {          // two key tiles per round: their 8 fragments are requested together
+        h8 kf[2][2], vf[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = (k0 + i) * 16 + c;
+          kf[i][0] = frag_t(ktile, row, g); kf[i][1] = frag_t(ktile, row, 4 + g);
+          vf[i][0] = frag_t(vtile, row, g); vf[i][1] = frag_t(vtile, row, 4 + g);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int kt = k0 + i;
+          f4 zz = {0.f, 0.f, 0.f, 0.f};
+          f4 sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][0], qf[0], zz, 0, 0, 0);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[i][1], qf[1], sc, 0, 0, 0);
+          f4 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[i][0], df[0], zz, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[i][1], df[1], dp, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], C1, -lq));
+            if (CAUSAL) pv = (key < L && key <= qi) ? pv : 0.f;
+            else if (kt >= KTL - 2) pv = key < L ? pv : 0.f;
+            ds16[kt][r] = (half_t)(pv * (dp[r] - dlq));            // the 1/8 of dS is applied to the 16 results below
+          }
+        }
+      }
+      f4 acc[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KTL / 2; ++ks)
+          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag_swz(ktile, ks * 32, ks * 32 + 16, dt * 16, lane),
+                                                           cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[dt], 0, 0, 0);
+        acc[dt] *= 0.125f;
+      }
+      if (qt + NW < nt) load_tile(qt + NW);          // the wave's second tile: requested under the dQ stores of the first
+      store_rows(dq, ld, acc, qt * 16, L, scr, lane);
+      if (want_dbias) add_rounded(csum, acc);        // queries past L are exact zeros (their dS is)
+    }
+    if (want_dbias) store_colsum(red + wid * 64, csum, lane);
+    for (int r = nt * 16 + tid; r < ROWS; r += 64 * NW) {     // whole tiles of padding: phase 2 walks every query of the image
+      lse_s[r] = INFINITY;
+      del_s[r] = 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the Q / dO images has landed
+    __syncthreads();                                          // ... everyone's, and every delta / lse is in LDS
+    // ---- phase 2: dV and dK.  The K / V fragments of this wave's (at most two) key tiles first; then K and V are dead
+    h8 kfr[2][2], vfr[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int kt = min(wid + s2 * NW, ROWS / 16 - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kfr[s2][ks] = frag_t(ktile, kt * 16 + c, ks * 4 + g);
+        vfr[s2][ks] = frag_t(vtile, kt * 16 + c, ks * 4 + g);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (head + (int)gridDim.x < total) {           // the next head's K and V, under this phase
+      const int hn = head + gridDim.x, n2 = hn / p.H, h2 = hn % p.H;
+      const __amdgpu_buffer_rsrc_t r = rsrc_qkv(n2);
+      dma_image<ROWS, NW>(r, ktile, (unsigned)((D + h2 * DH) * 2), ldb, wid, lane);
+      dma_image<ROWS, NW>(r, vtile, (unsigned)((2 * D + h2 * DH) * 2), ldb, wid, lane);
+    }
+    f4 csk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { csum[dt] = f4{0.f, 0.f, 0.f, 0.f}; csk[dt] = f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int kt = wid + s2 * NW;
+      if (kt >= nt || HMMC_ATTN_SKIP == 2) break;
+      const int key = kt * 16 + c;
+      const bool key_ok = key < L;
+      const h8 (&kf)[2] = kfr[s2];
+      const h8 (&vf)[2] = vfr[s2];
+      f4 av[4], ak[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { av[dt] = f4{0.f, 0.f, 0.f, 0.f}; ak[dt] = f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int qp = 0; qp < KTL / 2; ++qp) {
+        h4 p16[2], ds16[2];
+        h8 qf[2][2], df[2][2];
+        f4 lr[2], dl[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                // both query tiles of the pair: fragments, lse and delta requested together
+          const int qt = 2 * qp + e;
+          qf[e][0] = frag_t(qtile, qt * 16 + c, g); qf[e][1] = frag_t(qtile, qt * 16 + c, 4 + g);
+          df[e][0] = frag_t(dtile, qt * 16 + c, g); df[e][1] = frag_t(dtile, qt * 16 + c, 4 + g);
+          lr[e] = *reinterpret_cast<const f4*>(lse_s + qt * 16 + 4 * g);
+          dl[e] = *reinterpret_cast<const f4*>(del_s + qt * 16 + 4 * g);
+        }
+        h8 dT[4], qT[4];                             // dO^T / Q^T of the pair, used after the exponentials
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dT[dt] = tr_frag_swz(dtile, qp * 32, qp * 32 + 16, dt * 16, lane);
+          qT[dt] = tr_frag_swz(qtile, qp * 32, qp * 32 + 16, dt * 16, lane);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int qt = 2 * qp + e;
+          f4 z = {0.f, 0.f, 0.f, 0.f};
+          f4 sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[e][0], kf[0], z, 0, 0, 0);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[e][1], kf[1], sc, 0, 0, 0);
+          f4 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[e][0], vf[0], z, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(df[e][1], vf[1], dp, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = qt * 16 + 4 * g + r;
+            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], C1, -lr[e][r]));   // 0 for queries past L (lse = +inf)
+            pv = (key_ok && (!CAUSAL || key <= qi)) ? pv : 0.f;
+            p16[e][r] = (half_t)pv;
+            ds16[e][r] = (half_t)(pv * (dp[r] - dl[e][r]));         // the 1/8 of dS is applied to dK below
+          }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dT[dt], cat4(p16[0], p16[1]), av[dt], 0, 0, 0);
+          ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qT[dt], cat4(ds16[0], ds16[1]), ak[dt], 0, 0, 0);
+        }
+#if HMMC_ATTN_PIN
+        __builtin_amdgcn_sched_barrier(0);           // keep the scheduler from hoisting the next pairs' 28 fragment reads over this one
+#endif
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) ak[dt] *= 0.125f;
+      store_rows(dv, ld, av, kt * 16, L, scr, lane);
+      store_rows(dk, ld, ak, kt * 16, L, scr, lane);
+      if (want_dbias) { add_rounded(csum, av); add_rounded(csk, ak); }   // keys past L are exact zeros (P and dS are)
+    }
+    // in_proj bias-gradient partials of this (sequence, head): the waves' sums in wave order (fixed: bit-stable)
+    if (want_dbias) {
+      store_colsum(red + (1 * NW + wid) * 64, csk, lane);
+      store_colsum(red + (2 * NW + wid) * 64, csum, lane);
+      __syncthreads();
+      if (tid < 192) {
+        const int type = tid >> 6, d = tid & 63;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[(type * NW + w) * 64 + d];
+        p.dbias[(long)n * 3 * D + type * D + h * DH + d] = t;
+      }
+    }
+    // the loop top waits for the K / V images of the next head and passes a barrier before anything of this head's LDS state
+    // (Q / dO images, delta, lse, red) is written again
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
@@ -414,7 +500,9 @@ static void launch_long_bwd2(const AttnArgs& p, hipStream_t stream) {
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool done[HMMC_MAX_DEVICES] = {false};
   hmmc_allow_lds((const void*)attn_long_bwd_kernel<KTL, NW, CAUSAL>, LDS, done);
-  hipLaunchKernelGGL((attn_long_bwd_kernel<KTL, NW, CAUSAL>), dim3((unsigned)(p.nseq * p.H)), dim3(64 * NW), LDS, stream, p);
+  const long total = (long)p.nseq * p.H;
+  const long wgs = hmmc_num_cus();                                         // persistent: one workgroup per CU
+  hipLaunchKernelGGL((attn_long_bwd_kernel<KTL, NW, CAUSAL>), dim3((unsigned)(total < wgs ? total : wgs)), dim3(64 * NW), LDS, stream, p);
 }
 template <int KTL, int NW>
 static void launch_long_bwd(const AttnArgs& p, hipStream_t stream) {
@@ -428,7 +516,7 @@ int hmmc_attention_long_bwd(const AttnArgs& p, hipStream_t stream) {
     // 8 waves (two per SIMD, up to 256 registers each: phase 2 holds 64 accumulator + 64 transposed-operand registers).  One wave
     // per tile - 13 waves for ViT-B/16's 13 tiles - would need 128 registers per wave and spills ~100 of them; 7 waves (13 tiles
     // in two even rounds) measured the same as 8 (480 vs 487 us at 384 x 197 x 12).
-    case 6: launch_long_bwd<6, 6>(p, stream); break;
+    case 6: launch_long_bwd<6, 8>(p, stream); break;
     case 8: launch_long_bwd<8, 8>(p, stream); break;
     case 10: launch_long_bwd<10, 8>(p, stream); break;
     case 12: launch_long_bwd<12, 8>(p, stream); break;
