@@ -508,6 +508,11 @@ class BirdModel(BirdPreTrainedModel):
                                        self.weight_VTM_finetune, self.weight_FTM_finetune, scale)
         if self.task_config.local_rank == 0 and getattr(self.task_config, "logdir", None):
             self.task_config.writer.add_scalar("loss", float(loss), global_step=global_step)
+        # a token id outside the embedding table raises IndexError in the reference; here the kernel sets a device flag, read at
+        # the reference's own logging interval (main_task_retrieval.py:304-312 reads the loss on the host there anyway)
+        nd = getattr(self.task_config, "n_display", 0)
+        if nd and global_step and global_step % nd == 0:
+            ops.raise_on_device_errors(video.device)
         return loss
 
 
