@@ -30,6 +30,9 @@
                      // 3 / 4 / 5: s_memrealtime stamps of the third work item into p.ws (scratch/gemm_stamps.py), 4 = 1 + stamps, 5 = 2 + stamps
 #endif
 
+#ifndef HMMC_PHASES
+#define HMMC_PHASES 2  // segments of the 256x256 K-loop per K-tile and group: 2 x 32 MFMAs (product); 4 x 16 MFMAs = rounds 1-2 (scratch)
+#endif
 #ifndef HMMC_PF
 #define HMMC_PF 6     // prefetch distance of the 256x256 K-loop in half-tiles (scratch experiments build 4)
 #endif
@@ -509,25 +512,25 @@ __device__ __forceinline__ void gemm_f16_body(const GemmArgs& p, const GemmGroup
 
   if constexpr (MT == 8 && NT == 4) {
     // ---- 256x256 tile, ping-pong schedule.  The two waves of a SIMD are wid and wid + 4, i.e. the wm = 0 and wm = 1
-    // waves of one wn.  A K-tile is 4 phases of 16 MFMAs (one 64x32 quadrant x K = 64); each phase is a LOAD segment
-    // (LDS fragment reads for this phase + the LDS-DMA of one half-tile of a later K-tile), a barrier, a MATRIX
-    // segment, a barrier.  The wm = 1 group runs one barrier behind, so on every SIMD one wave's matrix segment
-    // sits beside its partner's load segment.
-    //   phase   reads (ds_read)      MFMA quadrant     stages (LDS-DMA, 2 loads/thread)
-    //     1     A0 (8) + B0 (4)      (a0, b0)          B1 of K-tile t+1
-    //     2     B1 (4)               (a0, b1)          A1 of K-tile t+1
-    //     3     A1 (8)               (a1, b1)          A0 of K-tile t+2
-    //     4     - (B0 kept)          (a1, b0)          B0 of K-tile t+2
-    // every load segment ends with s_waitcnt vmcnt(8): all but the four most recently staged halves have landed
-    // WAR: a half image is restaged two phases or more after the phase that last read it, so with the groups one
-    // barrier apart every read has retired (lgkmcnt before that phase's MFMAs) before the DMA is even issued.
-    // RAW: a half is read four phases after it was staged.  The vmcnt(8) that closes the load segment of phase q leaves
-    // only the four youngest halves (8 loads per thread) in flight, so the half read in phase q + 1 - staged four
-    // phases before that - has landed, and the wait precedes the barriers both groups pass before that read.  One
-    // counted wait per phase instead of a vmcnt(4) once per K-tile gives every half four phases to arrive instead of
-    // two: operands that stream from HBM (weight gradients) no longer stall the K-tile on their way in.  Past the
-    // last K-tile the DMA is still issued, out of range (reads as zero into a dead image), so the count stays exact;
-    // epilogue stores only make the wait stricter.
+    // waves of one wn.  A K-tile is 2 segments of 32 MFMAs per wave (a 64x64 half of the wave's tile x K = 64); each is a
+    // LOAD segment (LDS fragment reads + LDS-DMA of half-tiles of later K-tiles), a barrier, a MATRIX segment, a barrier.
+    // The wm = 1 group runs one barrier behind, so on every SIMD one wave's matrix segment sits beside its partner's load
+    // segment.  K-tile t lives in stage t & 1 as four half images A0, A1 (128 rows each), B0, B1:
+    //   segment   reads (ds_read)              MFMA                      stages (LDS-DMA, 2 loads/thread and half)
+    //     1       B0 (4) + A0 (8) + B1 (4)     (a0, b0), (a0, b1)        A1 of K-tile t+1
+    //     2       A1 (8)                       (a1, b1), (a1, b0)        A0, B0, B1 of K-tile t+2 (the images segment 1 read)
+    // Every load segment ends with s_waitcnt vmcnt(8) lgkmcnt(0): all but the four most recently staged halves have landed,
+    // and the wave's own fragment reads have retired, before the barrier.
+    // WAR: an image is restaged in the first load segment after a barrier that follows the last read of it by EITHER group
+    // (segment 2 of K-tile t restages what both groups read in their segment 1; segment 1 of K-tile t+1 restages A1, read in
+    // both groups' segment 2 of K-tile t), and those reads retired before that barrier.
+    // RAW: every half is waited for in the load segment one K-tile (four barriers) after the one that staged it, and that
+    // wait precedes the barriers both groups pass before the read: a half has a whole K-tile to arrive, against half a
+    // K-tile for the last-staged half of the four-phase schedule of rounds 1-2 (-DHMMC_PHASES=4), which also paid eight
+    // barriers per K-tile instead of four and ran its heaviest load segment (12 reads + a half) beside only 16 MFMAs.
+    // Measured on a layer's twelve GEMMs (scratch/ab_lib.sh): 6 460 -> 5 960 us; the weight gradients and the m-major data
+    // gradients, whose operands stream from HBM, gain most (+12-14 %).  Past the last K-tile the DMA is still issued, out of
+    // range (reads as zero into a dead image), so the count stays exact; epilogue stores only make the wait stricter.
     constexpr int HALF = 128 * BKT * 2;
     // operands of the problem being STAGED (the prefetch runs ahead of the computation across item boundaries, so under GRP
     // it can already be in the next problem); without GRP these never change
@@ -576,6 +579,12 @@ __device__ __forceinline__ void gemm_f16_body(const GemmArgs& p, const GemmGroup
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
       acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[ks][j], af[ks][i], acc[I0 + i][J0 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0); } while (0)
+#if HMMC_PHASES == 2
+    stage_a(0); stage_b(0); stage_b(1); stage_a(1);
+    s_advance();
+    stage_a(0); stage_b(0); stage_b(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // A0, B0, B1 of the first K-tile have landed
+#else
 #if HMMC_PF == 6
 #define HMMC_VMW "s_waitcnt vmcnt(8)"
 #define HMMC_ST1() stage_b(1)
@@ -595,12 +604,47 @@ __device__ __forceinline__ void gemm_f16_body(const GemmArgs& p, const GemmGroup
     s_advance();
 #endif
     asm volatile(HMMC_VMW ::: "memory");
+#endif
     HMMC_BAR();
     if (wm == 1) HMMC_BAR();
     const int arow = wm * 64, brow = wn * 32;
     while (true) {
       const char* base = smem + buf * (4 * HALF);
       h8 af[2][4], b0f[2][2], b1f[2][2];
+#if HMMC_PHASES == 2
+      // segment 1
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b0f[ks][j] = read_frag<BK, 128>(base + 2 * HALF, brow + j * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<AK, 128>(base, arow + i * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b1f[ks][j] = read_frag<BK, 128>(base + 3 * HALF, brow + j * 16, ks, lane);
+      stage_a(1); s_advance();
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      HMMC_BAR();
+      HMMC_MM(0, 0, b0f);
+      HMMC_MM(0, 2, b1f);
+      HMMC_BAR();
+      HMMC_STAMP();
+      // segment 2
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<AK, 128>(base + HALF, arow + i * 16, ks, lane);
+      stage_a(0); stage_b(0); stage_b(1);
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      HMMC_BAR();
+      HMMC_MM(4, 2, b1f);
+      HMMC_MM(4, 0, b0f);
+      HMMC_BAR();
+      HMMC_STAMP();
+#else
       // phase 1
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -645,6 +689,7 @@ __device__ __forceinline__ void gemm_f16_body(const GemmArgs& p, const GemmGroup
       HMMC_MM(4, 0, b0f);
       HMMC_BAR();
       HMMC_STAMP();
+#endif
       int n_item, n_split, n_tm, n_tn, n_kt, n_end;
       next_pos(n_item, n_split, n_tm, n_tn, n_kt, n_end);
       if (kt + 1 >= kt_end) {
