@@ -10,6 +10,7 @@
 // 64x64x16 block tile, 4 waves (2x2, 32x32 each), register-staged double buffering; MFMA operands
 // swapped (A-operand = B rows) so a lane owns 4 consecutive n of one row: 16-byte stores.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -178,6 +179,83 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(G32 p) {
     const f4 t = (red[0][w][lane] + red[1][w][lane]) + (red[2][w][lane] + red[3][w][lane]);
     store_tile16(p, t, m0 + r, n0 + 16 * w + 4 * kg);
   }
+}
+
+// ---- the same scheme on larger tiles: (16 RM) x (16 RN) outputs per workgroup, K split over its four waves ------------------
+// The 16 x 32 tile above re-reads 0.19 B of operand per flop from L2, which caps it at a third of the matrix rate; a 64 x 64
+// tile needs 0.06 B/flop, and one wave per SIMD issuing 16 independent 16x16x4 MFMAs per sub-step keeps the matrix pipe full
+// without LDS staging or barriers in the K loop.  Used where the 64x64 LDS kernel is bound by the length of K (a workgroup
+// per CU or fewer: the temporal transformer, the MoCo query gradient) - each wave's dependent chain is K/4 long here.
+// The four partial tiles meet in LDS; wave w finishes the tiles t with t % 4 == w, summed in a fixed order.
+template <bool AV, bool BV, int RM, int RN>
+__global__ __launch_bounds__(256) void gemm_f32_wavek_kernel(G32 p) {
+  extern __shared__ __attribute__((aligned(16))) char wk_smem[];
+  f4 (*red)[RM * RN][64] = reinterpret_cast<f4 (*)[RM * RN][64]>(wk_smem);          // [wave][tile][lane]
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntn = (p.N + 16 * RN - 1) / (16 * RN);
+  const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+  const int m0 = tm * 16 * RM, n0 = tn * 16 * RN;
+  const int r = lane & 15, kg = lane >> 4;
+  const float* pa[RM];
+  const float* pb[RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) pa[i] = p.A + (long)min(m0 + 16 * i + r, p.M - 1) * p.sam;
+#pragma unroll
+  for (int j = 0; j < RN; ++j) pb[j] = p.B + (long)min(n0 + 16 * j + r, p.N - 1) * p.sbn;
+  f4 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  constexpr int PD = RM + RN <= 4 ? 4 : RM + RN <= 8 ? 3 : 2;    // steps of operand fragments in flight (RM + RN registers x 4 each)
+  const int nkt = (p.K + 15) / 16;
+  const int nj = nkt > w ? (nkt - w + 3) / 4 : 0;                // this wave's steps: kt = w + 4 j
+  f4 fa[PD][RM], fb[PD][RN];
+  auto fetch = [&](int j, f4 (&a)[RM], f4 (&b)[RN]) {
+    const int k = (w + 4 * j) * 16 + 4 * kg;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) a[i] = small_frag<AV>(pa[i], p.sak, p.K, k);
+#pragma unroll
+    for (int jn = 0; jn < RN; ++jn) b[jn] = small_frag<BV>(pb[jn], p.sbk, p.K, k);
+  };
+#pragma unroll
+  for (int s = 0; s < PD; ++s) fetch(s, fa[s], fb[s]);
+  auto step = [&](int j, f4 (&a)[RM], f4 (&b)[RN]) {
+    const int k = (w + 4 * j) * 16 + 4 * kg;
+    f4 ca[RM], cb[RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) ca[i] = zero_past(a[i], k, p.K);
+#pragma unroll
+    for (int jn = 0; jn < RN; ++jn) cb[jn] = zero_past(b[jn], k, p.K);
+    fetch(j + PD, a, b);
+    __builtin_amdgcn_sched_barrier(0);     // keep the refill ahead of this step's MFMAs
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < RN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[jn][s], ca[i][s], acc[i][jn], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int j = 0; j < nj; j += PD) {       // no branches inside: steps past nj multiply zeros (k >= K)
+#pragma unroll
+    for (int s = 0; s < PD; ++s) step(j + s, fa[s], fb[s]);
+  }
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < RN; ++jn) red[w][i * RN + jn][lane] = acc[i][jn];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < RN; ++jn) {
+      const int t = i * RN + jn;
+      if ((t & 3) != w) continue;                                 // wave-uniform
+      const f4 v = (red[0][t][lane] + red[1][t][lane]) + (red[2][t][lane] + red[3][t][lane]);
+      store_tile16(p, v, m0 + 16 * i + r, n0 + 16 * jn + 4 * kg);
+    }
 }
 
 // ---- eval scorer epilogue: video logit + mean of the top-k frame logits, straight from the accumulators -----------------
@@ -431,7 +509,44 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
   const double mnk = (double)M * N * K;
   const double t_small = 3.0 + mnk * ((sak == 1 && sbk == 1) ? 6.0e-8 : 3.9e-8);
   const double t_tiled = 3.0 + (K / 16.0) * 0.40 * (0.4 + 0.6 * (double)((blocks + num_cu - 1) / num_cu));
-  if (t_small < t_tiled) {
+  // The wave-split-K kernel on (16 RM) x 64 tiles, for problems it covers with at most one workgroup per CU (more than one per CU
+  // share the matrix pipe at ~0.7 of its rate: measured).  Matrix-rate bound: 2 RM RN K cycles per tile; the smallest RM that
+  // fits the CUs gives the shortest chain.  Measured against the other two kernels on every fp32 shape of the path
+  // (scratch/gemm32_pick.py): ahead for K >= 1536 (data / weight gradients and c_proj of the temporal transformer, the MoCo
+  // query gradient, the MLM data gradient), behind for K = 512, where the fixed ~6 us of fill and reduction decide.
+  {
+    static const bool off = std::getenv("HMMC_NO_F32_WAVEK") != nullptr;          // A/B runs
+    static const char* force_s = std::getenv("HMMC_F32_PICK");                    // scratch: 1 small, 2 tiled, 3.. wave-split-K RM = 2, 3, 4, 6
+    const int force = force_s ? atoi(force_s) : 0;
+    const bool av = sak == 1 && p.avec && !(K & 3), bv = sbk == 1 && p.bvec && !(K & 3);
+    static const int rms[4] = {2, 3, 4, 6};
+    double best = t_small < t_tiled ? t_small : t_tiled;
+    int rm = 0;
+    if (force >= 3 && force <= 6) rm = rms[force - 3];
+    for (int c = 0; c < 4 && !off && !force; ++c) {
+      const long tiles = (long)((M + 16 * rms[c] - 1) / (16 * rms[c])) * ((N + 63) / 64);
+      if (tiles > num_cu) continue;
+      const double t = 6.0 + (double)K * rms[c] * 4 * (2.0 / 1900.0) / 0.85;
+      if (t < best) { best = t; rm = rms[c]; }
+      break;                                                                      // larger tiles only lengthen the chain
+    }
+    if (rm) {
+      const long tiles = (long)((M + 16 * rm - 1) / (16 * rm)) * ((N + 63) / 64);
+      const int smem = 4 * rm * 4 * 1024;
+#define HMMC_WK1(AVV, BVV, RMM) do { static bool done_[HMMC_MAX_DEVICES] = {false}; \
+        if (smem > 64 * 1024) hmmc_allow_lds((const void*)gemm_f32_wavek_kernel<AVV, BVV, RMM, 4>, smem, done_); \
+        hipLaunchKernelGGL((gemm_f32_wavek_kernel<AVV, BVV, RMM, 4>), dim3((unsigned)tiles), dim3(256), smem, stream, p); } while (0)
+#define HMMC_WK(AVV, BVV) do { if (rm == 2) HMMC_WK1(AVV, BVV, 2); else if (rm == 3) HMMC_WK1(AVV, BVV, 3); \
+                               else if (rm == 4) HMMC_WK1(AVV, BVV, 4); else HMMC_WK1(AVV, BVV, 6); } while (0)
+      if (av && bv) HMMC_WK(true, true); else if (av) HMMC_WK(true, false); else if (bv) HMMC_WK(false, true); else HMMC_WK(false, false);
+#undef HMMC_WK
+#undef HMMC_WK1
+      return hmmc_launch_status();
+    }
+  }
+  static const char* force2_s = std::getenv("HMMC_F32_PICK");
+  const int force2 = force2_s ? atoi(force2_s) : 0;
+  if (force2 == 1 || (force2 != 2 && t_small < t_tiled)) {
     long small = (long)((M + 15) / 16) * ((N + 31) / 32);
     const bool av = sak == 1 && p.avec && !(K & 3), bv = sbk == 1 && p.bvec && !(K & 3);
     auto k = av ? (bv ? gemm_f32_small_kernel<true, true> : gemm_f32_small_kernel<true, false>)
