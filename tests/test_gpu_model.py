@@ -66,6 +66,32 @@ def test_gemm_f32_all_orientations():
     close(gq, href * torch.sigmoid(1.702 * href), 1e-4, 1e-5, "qgelu")
 
 
+@pytest.mark.parametrize("M,N,K", [(3072, 512, 2048), (1536, 512, 2048), (2048, 512, 1536), (700, 512, 4096), (1000, 500, 2052),
+                                   (333, 260, 3001)])
+def test_gemm_f32_long_k_single_round_exact_integers(M, N, K):
+    """Shapes the fp32 dispatcher gives to the wave-split-K kernel (at most one (16 RM) x 64 tile per CU, long K; tile heights
+    96 / 48 / 64 / 32, ragged edges, K % 4 != 0 = the scalar-load variants), in the three operand orientations of the path
+    (x W^T, dy W, dy^T x; reference modules/module_cross.py:114-149).  Integer-valued operands: every product and partial
+    sum is exact in fp32, so the result must EQUAL the fp64 product whatever the order of the four waves' partial tiles."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
+    b = torch.randint(-3, 4, (N, K), generator=g).float().to(DEV)
+    bias = torch.randint(-5, 6, (N,), generator=g).float().to(DEV)
+    ref = (a.double() @ b.double().t()).float()
+    bt, at = b.t().contiguous(), a.t().contiguous()
+    c1 = ops.gemm_f32(a, b, M, N, K, (K, 1), (1, K))
+    c2 = ops.gemm_f32(a, bt, M, N, K, (K, 1), (N, 1), alpha=2.0, bias=bias)
+    c3 = ops.gemm_f32(at, bt, M, N, K, (1, M), (N, 1))
+    assert torch.equal(c1, ref), "x W^T"
+    assert torch.equal(c2, 2 * ref + bias), "dy W (+ alpha, bias)"
+    assert torch.equal(c3, ref), "dy^T x"
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = torch.randn(N, K, generator=g).to(DEV)
+    y = ops.gemm_f32(x, w, M, N, K, (K, 1), (1, K))
+    close(y, x.double() @ w.double().t(), 1e-4 * K / 512, 1e-5, "random operands")
+    assert torch.equal(y, ops.gemm_f32(x, w, M, N, K, (K, 1), (1, K))), "two launches, same bits"
+
+
 @pytest.mark.parametrize("tag", ["head_ft_small", "head_ft_c2"])
 def test_finetune_head_vs_reference_golden(tag):
     g = golden(tag)
