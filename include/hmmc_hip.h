@@ -150,7 +150,11 @@ int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, c
 /* fp32 MFMA GEMM (exact f32 FMA chain) with general strides: C[m][n] = epi(alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]);
  * one stride of each operand must be 1.  Epilogue flags as hmmc_gemm_f16 plus HMMC_EPI_RELU; QuickGELU is evaluated in fp32.
  * Temporal transformer (modules/module_cross.py:114-149), similarity matrices (modules/modeling.py:207-229,286-313),
- * projector MLPs (:788-807), MLM head (modules/module_cross.py:308-357). */
+ * projector MLPs (:788-807), MLM head (modules/module_cross.py:308-357).
+ * Three kernels behind one entry point, picked by an estimate of their times: 64x64x16 tiles staged through LDS (many tiles),
+ * 16x32 tiles whose four waves split K with operands straight from global memory (few tiles), and the same scheme on
+ * (32..96)x64 tiles for problems of at most one tile per CU with K >= ~1 536.  Every kernel sums in a fixed order: the
+ * result of a call depends on its arguments only (bit-identical from launch to launch), not on which kernel another shape took. */
 #define HMMC_EPI_RELU 16
 int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn,
                   int ldc, float alpha, const float* bias, const float* resid, float* aux_out, const float* aux_in,
