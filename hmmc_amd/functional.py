@@ -57,6 +57,41 @@ def _wgrad(dy, x):
     return _wgrad16(dy, x) if dy.dtype == torch.float16 else ops.wgrad_f32(dy, x)
 
 
+# The im2col of a step's frames depends on the frames alone.  The pre-training model encodes the SAME frames with the online and
+# the momentum tower (reference modules/modeling.py:347,356): inside `share_patches()` the second VitEmbedFn call on the same
+# tensor (same storage, version, stream, patch size and dtype) takes the first one's patch matrix instead of re-reading the video.
+_PATCH_SHARE = {"on": False, "key": None, "val": None}
+
+
+class share_patches:
+    def __enter__(self):
+        _PATCH_SHARE.update(on=True, key=None, val=None)
+        return self
+
+    def __exit__(self, *exc):
+        _PATCH_SHARE.update(on=False, key=None, val=None)
+        return False
+
+
+def _patches_of(video4d, p, dtype, frame_index):
+    key = None
+    if _PATCH_SHARE["on"] and video4d.is_cuda and not os.environ.get("HMMC_NO_PATCH_SHARE"):
+        key = (video4d.data_ptr(), video4d._version, tuple(video4d.shape), video4d.dtype, p, dtype,
+               None if frame_index is None else (frame_index.data_ptr(), frame_index._version, tuple(frame_index.shape)),
+               torch.cuda.current_stream(video4d.device).cuda_stream)
+        if _PATCH_SHARE["key"] == key:
+            return _PATCH_SHARE["val"]
+    if video4d.dtype == torch.uint8:
+        patches = ops.patchify_u8(video4d, p, frame_index=frame_index, dtype=dtype)
+    else:
+        if frame_index is not None:
+            raise TypeError("frame sampling on the device takes the stored uint8 frames")
+        patches = ops.patchify(video4d, p, dtype=dtype)
+    if key is not None:
+        _PATCH_SHARE.update(key=key, val=patches)
+    return patches
+
+
 class VitEmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, video4d, conv_w, cls, pos, ln_w, ln_b, frame_index=None):
@@ -66,12 +101,7 @@ class VitEmbedFn(torch.autograd.Function):
         # [n*L, 3pp] in the conv weight's dtype (image.type(self.dtype), modules/module_cross.py:224), class rows zero; uint8
         # frames are normalised on the fly (CLIP mean / std) and, with a frame index, picked out of the stored frames in place
         # (the loader's frame sampling)
-        if video4d.dtype == torch.uint8:
-            patches = ops.patchify_u8(video4d, p, frame_index=frame_index, dtype=conv_w.dtype)
-        else:
-            if frame_index is not None:
-                raise TypeError("frame sampling on the device takes the stored uint8 frames")
-            patches = ops.patchify(video4d, p, dtype=conv_w.dtype)
+        patches = _patches_of(video4d, p, conv_w.dtype, frame_index)
         x0 = _linear(patches, conv_w.view(D, -1))
         ops.vit_embed_(x0, cls, pos, L)
         x, mean, rstd = ops.layernorm_fwd(x0, ln_w, ln_b, 1e-5)

@@ -327,6 +327,8 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
                 t.record_stream(side)
             with torch.cuda.stream(side):
                 tag_fea, title_fea, mlm_hidden = online_text()
+        share = Fn.share_patches()                      # the momentum tower below encodes the same frames: one im2col for both
+        share.__enter__()
         v_fea, frame_fea = self.visual_encoder(video, video_frame)
         if not overlap:
             tag_fea, title_fea, mlm_hidden = online_text()
@@ -345,6 +347,7 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
             else:
                 tag_fea_k, title_fea_k = key_text()
             v_fea_k, frame_fea_k = self.visual_encoder_k(video, video_frame)
+            share.__exit__(None, None, None)
             frame_proj_k = self._mlp(self.v_projector_k, frame_fea_k.reshape(-1, hidden)).view(bs, frame, hidden)
         if overlap:
             cur.wait_stream(side)
