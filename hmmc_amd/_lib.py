@@ -20,6 +20,13 @@ SIGNATURES = {
     "hmmc_gemm_f16_workspace": ("iii", "z"),
     "hmmc_gemm_f16_colsum_rows": ("iii", "z"),
     "hmmc_gemm_f16": ("pppiiiiiiiippppipzp", "i"),
+    "hmmc_gemm_f16_fold": ("pppiiiiiippipppp", "i"),
+    "hmmc_ln_fold_prep": ("pppppppiip", "i"),
+    "hmmc_rowstat": ("ppiilfp", "i"),
+    "hmmc_rowstat_finalize": ("ppiiifp", "i"),
+    "hmmc_tower_fold_bytes": ("lii", "z"),
+    "hmmc_tower_fwd_fused": ("pppppiiiiiifipzp", "i"),
+    "hmmc_vit_embed_ln": ("pppppppppiiifip", "i"),
     "hmmc_gemm_f16_wgrad_group_workspace": ("ppii", "z"),
     "hmmc_gemm_f16_wgrad_group": ("pppppiipzp", "i"),
     "hmmc_gemm_reserve_cus": ("i", "i"),

@@ -41,13 +41,18 @@ namespace {
 
 constexpr int BKT = 64;
 
-enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32, EPI_SAVE_DGELU = 64, EPI_MULAUX = 128 };
+enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32, EPI_SAVE_DGELU = 64, EPI_MULAUX = 128,
+       EPI_LNFOLD = 256,      // acc -> a_r * acc + (b_r * c_n + d_n): LayerNorm folded into the GEMM (rowstat, colterms), see below
+       EPI_ROWSTAT = 512 };   // + per-row (sum, sum of squares) of the fp16 values written, one pair per 64-column block (stat_part)
 
 struct GemmArgs {
   const half_t* A; const half_t* B; half_t* C;
   const half_t* bias; const half_t* resid; half_t* aux_out; const half_t* aux_in;
   float* ws;
   float* csum;                  // EPI_COLSUM: fp32 [row blocks of 128 (256x256 tile) or 64 rows][N] partial column sums of C
+  const float* rowstat;         // EPI_LNFOLD: [M][2] = (rstd_r, -rstd_r * mean_r) of the rows of A
+  const float* colterms;        // EPI_LNFOLD: [2][N] = c_n = sum_k B[n][k] (B = gamma o W), d_n = sum_k beta_k W[n][k] + bias_n
+  float* stat_part;             // EPI_ROWSTAT: [N / 64][M][2] = (sum, sum of squares) over the 64-column block of the row
   int M, N, K, lda, ldb, ldc;
   int flags, splitk, ktps;
   int slab;                     // 1: write the fp32 partial slab even when splitk == 1 (pieces along K, reduced by the host's launch)
@@ -213,6 +218,26 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
       bias[j] = f4{(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
     }
   }
+  // EPI_LNFOLD: y = LN(x) W^T + b evaluated as rstd_r (x (gamma o W)^T)[r][n] - rstd_r mean_r c_n + d_n on the RAW rows x: the
+  // normalised activations are never written or read (reference modules/module_clip.py:217-223,252-256: ln_1 -> in_proj,
+  // ln_2 -> c_fc).  The row pair (a_r, b_r) = (rstd_r, -rstd_r mean_r) of each of this lane's MT rows and the column pairs
+  // (c_n, d_n) of its 16 columns are requested up front.
+  f4 fold_c[4], fold_d[4];
+  f2 fold_r[MT];
+  if (flags & EPI_LNFOLD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 16 * j + 4 * g;
+      const int nn = (FULL || n < p.N) ? n : 0;
+      fold_c[j] = *reinterpret_cast<const f4*>(p.colterms + nn);
+      fold_d[j] = *reinterpret_cast<const f4*>(p.colterms + p.N + nn);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = FULL ? m_base + 16 * i + c : min(m_base + 16 * i + c, p.M - 1);
+      fold_r[i] = *reinterpret_cast<const f2*>(p.rowstat + 2 * (size_t)m);
+    }
+  }
   const bool has_src = flags & (EPI_DGELU | EPI_MULAUX | EPI_RESID);
   const char* src = reinterpret_cast<const char*>((flags & (EPI_DGELU | EPI_MULAUX)) ? p.aux_in : p.resid);
   constexpr int HB = MT > 4 ? 4 : MT;            // strips whose operand loads are in flight together (32 VGPRs)
@@ -293,9 +318,11 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
     }
     // pc / qc: the strip's result (and auxiliary result) as packed fp16, four 8-byte pieces in the MFMA layout
     u2 pc[4], qc[4];
+    float rs1 = 0.f, rs2 = 0.f;                    // EPI_ROWSTAT: this lane's part of the row's sum and sum of squares
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f4 v = acc[i][j];
+      if (flags & EPI_LNFOLD) v = fold_r[i][0] * v + (fold_r[i][1] * fold_c[j] + fold_d[j]);
       if (flags & EPI_BIAS) v += bias[j];
       if (flags & EPI_QGELU) {
         // QuickGELU with the reference's fp16 rounding points, two elements at a time.  The values that torch holds as
@@ -337,7 +364,18 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
       } else {
         out = v;
       }
-      pc[j] = u2{pk2(out[0], out[1]), pk2(out[2], out[3])};
+      const unsigned lo = pk2(out[0], out[1]), hi = pk2(out[2], out[3]);
+      pc[j] = u2{lo, hi};
+      if (flags & EPI_ROWSTAT) {
+        // (sum, sum of squares) of the ROUNDED values (v_dot2c_f32_f16: two elements per instruction, fp32 accumulation).
+        // From the scalars, not from pc[j][e]: hipcc 7.2 folds bit_cast<half2>(pc[j][1]) to the FIRST dword of the pair.
+        const h2v ones = h2v{(_Float16)1.0f, (_Float16)1.0f};
+        const h2v hl = __builtin_bit_cast(h2v, lo), hh = __builtin_bit_cast(h2v, hi);
+        rs1 = __builtin_amdgcn_fdot2(hl, ones, rs1, false);
+        rs2 = __builtin_amdgcn_fdot2(hl, hl, rs2, false);
+        rs1 = __builtin_amdgcn_fdot2(hh, ones, rs1, false);
+        rs2 = __builtin_amdgcn_fdot2(hh, hh, rs2, false);
+      }
     }
     if (want_csum) {                               // sums of the ROUNDED values, as a pass over the stored tensor would see
       const bool row_ok = FULL || m_base + 16 * i + c < p.M;
@@ -345,6 +383,14 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
 #pragma unroll
         for (int j = 0; j < 4; ++j) csum[j] += unpack2(pc[j][0], pc[j][1]);
       }
+    }
+    if (flags & EPI_ROWSTAT) {
+      // this lane's 16 columns of the row -> the row's 64-column block: the other columns sit in lanes c + 16, c + 32, c + 48
+      float s1 = rs1, s2 = rs2;
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      const int m = m_base + 16 * i + c;
+      if (g == 0 && (FULL || (m < p.M && n0 < p.N))) *reinterpret_cast<f2*>(p.stat_part + 2 * ((size_t)(n0 >> 6) * p.M + m)) = f2{s1, s2};
     }
     store_strip(p.C, i, pc);
     if (two) store_strip(p.aux_out, i, qc);      // the pre-activation or QuickGELU'(h), for the backward pass
@@ -870,6 +916,9 @@ void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stre
       case EPI_BIAS | EPI_QGELU: return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS | EPI_QGELU>(p, grid, stream);
       case EPI_BIAS | EPI_QGELU | EPI_SAVE_DGELU:
         return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS | EPI_QGELU | EPI_SAVE_DGELU>(p, grid, stream);
+      case EPI_LNFOLD: return launch_one<true, true, BM, BN, WM, WN, EPI_LNFOLD>(p, grid, stream);
+      case EPI_LNFOLD | EPI_QGELU: return launch_one<true, true, BM, BN, WM, WN, EPI_LNFOLD | EPI_QGELU>(p, grid, stream);
+      case EPI_BIAS | EPI_RESID | EPI_ROWSTAT: return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS | EPI_RESID | EPI_ROWSTAT>(p, grid, stream);
       default: return launch_one<true, true, BM, BN, WM, WN, -1>(p, grid, stream);
     }
   } else if (ak && !bk) {         // dgrad: dx = dy W
@@ -970,11 +1019,18 @@ extern "C" size_t hmmc_gemm_f16_workspace(int M, int N, int K) {
 
 // one launch (+ its split-K reduce).  slab_mode 0: ordinary call.  slab_mode 1 (pieces along K): the fp32 partial slabs go to
 // `workspace` (at least one, even without a split), no reduce; *slabs_out = slabs written.
+struct GemmExtra { const float* rowstat; const float* colterms; float* stat_part; };      // operands of EPI_LNFOLD / EPI_ROWSTAT
+
 static int gemm_f16_one(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                         int a_kmajor, int b_kmajor, const void* bias, const void* resid, void* aux_out,
                         const void* aux_in, int epilogue, void* workspace, size_t ws_bytes, hipStream_t stream,
-                        int slab_mode, int* slabs_out) {
+                        int slab_mode, int* slabs_out, const GemmExtra& ex = GemmExtra{nullptr, nullptr, nullptr}) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return HMMC_ERR_ARG;
+  if ((epilogue & EPI_LNFOLD) && (!ex.rowstat || !ex.colterms || (N & 3) || (((uintptr_t)ex.rowstat) & 7) || (((uintptr_t)ex.colterms) & 15)))
+    return HMMC_ERR_ARG;
+  if ((epilogue & EPI_ROWSTAT) && (!ex.stat_part || (((uintptr_t)ex.stat_part) & 7))) return HMMC_ERR_ARG;
+  if ((epilogue & EPI_ROWSTAT) && (N & 63)) return HMMC_ERR_UNSUPPORTED;             // whole 64-column blocks only
+  if ((epilogue & (EPI_LNFOLD | EPI_ROWSTAT)) && !(a_kmajor && b_kmajor)) return HMMC_ERR_UNSUPPORTED;
   if ((lda & 7) || (ldb & 7) || (ldc & 7) || (N & 7)) return HMMC_ERR_UNSUPPORTED;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)resid | (uintptr_t)aux_in | (uintptr_t)aux_out) & 15) return HMMC_ERR_UNSUPPORTED;
   if ((a_kmajor || b_kmajor) && (K % BKT)) return HMMC_ERR_UNSUPPORTED;   // k tail of a k-major operand
@@ -996,6 +1052,7 @@ static int gemm_f16_one(const void* A, const void* B, void* C, int M, int N, int
   p.aux_in = (const half_t*)aux_in;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.flags = epilogue;
   p.a_bytes = (unsigned)a_bytes; p.b_bytes = (unsigned)b_bytes;
+  p.rowstat = ex.rowstat; p.colterms = ex.colterms; p.stat_part = ex.stat_part;
   int nkt = (K + BKT - 1) / BKT;
   TileCfg cfg = pick_cfg(M, N, K, epilogue == 0);
   p.csum = nullptr;
@@ -1026,6 +1083,8 @@ static int gemm_f16_one(const void* A, const void* B, void* C, int M, int N, int
     double mn = (double)M * N;
     rec.bytes = 2.0 * ((double)M * K + (double)N * K + mn) + ((epilogue & EPI_BIAS) ? 2.0 * N : 0.0) +
                 2.0 * mn * (((epilogue & EPI_RESID) ? 1 : 0) + ((epilogue & (EPI_DGELU | EPI_MULAUX)) ? 1 : 0) + (aux_out ? 1 : 0));
+    if (epilogue & EPI_LNFOLD) rec.bytes += 8.0 * M + 8.0 * N;
+    if (epilogue & EPI_ROWSTAT) rec.bytes += 8.0 * M * (N / 64);
     rec.layout = a_kmajor ? (b_kmajor ? 0 : 1) : 2;
     (void)hipEventRecord(rec.e0, stream);
   }
@@ -1140,15 +1199,38 @@ extern "C" int hmmc_gemm_f16_wgrad_group(const void* const* dY, const void* cons
   return hmmc_launch_status();
 }
 
+static int gemm_f16_any(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                        int a_kmajor, int b_kmajor, const void* bias, const void* resid, void* aux_out,
+                        const void* aux_in, int epilogue, void* workspace, size_t ws_bytes, hipStream_t stream, const GemmExtra& ex);
+
 extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                              int a_kmajor, int b_kmajor, const void* bias, const void* resid, void* aux_out,
                              const void* aux_in, int epilogue, void* workspace, size_t ws_bytes, hipStream_t stream) {
+  if (epilogue & (EPI_LNFOLD | EPI_ROWSTAT)) return HMMC_ERR_ARG;      // those take hmmc_gemm_f16_fold's operands
+  return gemm_f16_any(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, resid, aux_out, aux_in, epilogue, workspace, ws_bytes,
+                      stream, GemmExtra{nullptr, nullptr, nullptr});
+}
+
+// The forward GEMM with a LayerNorm folded in (HMMC_EPI_LNFOLD: rowstat + colterms) and / or the row statistics of its output
+// emitted for the NEXT folded GEMM (HMMC_EPI_ROWSTAT: stat_part); k-major operands only, operands below 2 GiB.
+extern "C" int hmmc_gemm_f16_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                  const void* bias, const void* resid, int epilogue, const float* rowstat, const float* colterms,
+                                  float* stat_part, hipStream_t stream) {
+  if (epilogue & ~(EPI_BIAS | EPI_RESID | EPI_QGELU | EPI_LNFOLD | EPI_ROWSTAT)) return HMMC_ERR_UNSUPPORTED;
+  return gemm_f16_any(A, B, C, M, N, K, lda, ldb, ldc, 1, 1, bias, resid, nullptr, nullptr, epilogue, nullptr, 0, stream,
+                      GemmExtra{rowstat, colterms, stat_part});
+}
+
+static int gemm_f16_any(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                        int a_kmajor, int b_kmajor, const void* bias, const void* resid, void* aux_out,
+                        const void* aux_in, int epilogue, void* workspace, size_t ws_bytes, hipStream_t stream, const GemmExtra& ex) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc <= 0) return HMMC_ERR_ARG;
   const bool big_m = a_kmajor && (uint64_t)(M + 256) * lda * 2 >= PIECE_BYTES;
   const bool big_k = needs_k_pieces(K, lda, ldb, a_kmajor != 0, b_kmajor != 0);
   if (!big_m && !big_k)
     return gemm_f16_one(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, resid, aux_out, aux_in, epilogue, workspace,
-                        ws_bytes, stream, 0, nullptr);
+                        ws_bytes, stream, 0, nullptr, ex);
+  if (epilogue & (EPI_LNFOLD | EPI_ROWSTAT)) return HMMC_ERR_UNSUPPORTED;
   const char* a8 = (const char*)A;
   const char* b8 = (const char*)B;
   if (big_m && !big_k) {                         // pieces of whole 256-row tiles; the column-sum partials follow the rows

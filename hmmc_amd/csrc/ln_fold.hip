@@ -1,0 +1,152 @@
+// LayerNorm folded into the GEMM that consumes it (fp16 CLIP towers, forward without saved activations).
+//
+// Reference: modules/module_clip.py:252-256 - x = x + attention(ln_1(x)); x = x + mlp(ln_2(x)) - with the fp32 LayerNorm of
+// :217-223.  For a linear layer behind a LayerNorm,
+//     y[r][n] = sum_k ((x[r][k] - mean_r) rstd_r gamma_k + beta_k) W[n][k] + b_n
+//             = rstd_r (x W'^T)[r][n] - rstd_r mean_r c_n + d_n,    W' = gamma o W,  c_n = sum_k W'[n][k],  d_n = sum_k beta_k W[n][k] + b_n
+// so the GEMM can read the RAW residual stream x and apply the row pair (rstd_r, -rstd_r mean_r) and the column pair
+// (c_n, d_n) in its epilogue (HMMC_EPI_LNFOLD, gemm_f16.hip): LN(x) is never written to or read from HBM (2 x 472 MB per
+// ViT-B/32 layer at 153 600 tokens).  Pieces here:
+//   ln_fold_prep_kernel      W' (fp16, one rounding of gamma_k W[n][k]), c (sums of the ROUNDED W', so that the mean term cancels
+//                            exactly what the MFMA accumulated) and d, for up to 32 weight matrices in one launch
+//   rowstat_kernel           (rstd_r, -rstd_r mean_r) of fp16 rows: the tower's input (the residual stream of later layers gets
+//                            its statistics from the producing GEMM's epilogue, HMMC_EPI_ROWSTAT)
+//   rowstat_finalize_kernel  the per-64-column (sum, sum of squares) partials of HMMC_EPI_ROWSTAT -> (rstd_r, -rstd_r mean_r)
+// Rounding differs from the unfolded path (gamma o W is rounded to fp16 instead of LN(x)): this is the opt-in / no-grad
+// regime whose contract is the reference's own fp16-vs-fp32 envelope (tests/test_gpu_fold.py), not torch's rounding sequence.
+#include "common.h"
+
+namespace {
+
+constexpr int PREP_MAX = 32;
+struct PrepItem { const half_t* W; const float* gamma; const float* beta; const half_t* bias; half_t* Wf; float* cd; int N, row0; };
+struct PrepArgs { PrepItem it[PREP_MAX]; int n, K, rows; };
+
+// one wave per weight row
+__global__ __launch_bounds__(256) void ln_fold_prep_kernel(PrepArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  int e = 0;
+#pragma unroll 1
+  for (int t = 1; t < a.n; ++t) e = row >= a.it[t].row0 ? t : e;
+  const PrepItem& q = a.it[e];
+  const int n = row - q.row0;
+  const half_t* w = q.W + (size_t)n * a.K;
+  half_t* wf = q.Wf + (size_t)n * a.K;
+  float c = 0.f, d = 0.f;
+  for (int k = lane * 8; k < a.K; k += 512) {
+    const h8 wv = *reinterpret_cast<const h8*>(w + k);
+    const f4 g0 = *reinterpret_cast<const f4*>(q.gamma + k), g1 = *reinterpret_cast<const f4*>(q.gamma + k + 4);
+    const f4 b0 = *reinterpret_cast<const f4*>(q.beta + k), b1 = *reinterpret_cast<const f4*>(q.beta + k + 4);
+    h8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float wj = (float)wv[j];
+      const float gj = j < 4 ? g0[j] : g1[j - 4], bj = j < 4 ? b0[j] : b1[j - 4];
+      o[j] = (half_t)(gj * wj);
+      c += (float)o[j];
+      d += bj * wj;
+    }
+    *reinterpret_cast<h8*>(wf + k) = o;
+  }
+  c = wave_sum(c);
+  d = wave_sum(d);
+  if (lane == 0) {
+    q.cd[n] = c;
+    q.cd[q.N + n] = d + (q.bias ? (float)q.bias[n] : 0.f);
+  }
+}
+
+// (rstd, -rstd * mean) of fp16 rows; two-pass statistics in registers as ln_fwd_kernel (norm_elem.hip), D <= 1024
+__global__ __launch_bounds__(256) void rowstat_kernel(const half_t* __restrict__ x, float* __restrict__ stat, int rows, int D,
+                                                       long stride, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  const int nchunk = D / 8;
+  bool ok[2];
+  int ce[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { ok[i] = lane + 64 * i < nchunk; ce[i] = ok[i] ? (lane + 64 * i) * 8 : 0; }
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  h8 cur[2], nxt[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) cur[i] = *reinterpret_cast<const h8*>(x + (long)row * stride + ce[i]);
+  for (; row < rows; row += nwaves) {
+    const long nr = min(row + nwaves, rows - 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) nxt[i] = *reinterpret_cast<const h8*>(x + nr * stride + ce[i]);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (ok[i]) s += (float)cur[i][j];
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float dl = (float)cur[i][j] - mean; if (ok[i]) q += dl * dl; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) *reinterpret_cast<f2*>(stat + 2 * (size_t)row) = f2{rstd, -rstd * mean};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) cur[i] = nxt[i];
+  }
+}
+
+// part: [nparts][rows][2] (sum, sum of squares) -> stat[rows][2] = (rstd, -rstd * mean)
+__global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat, int nparts,
+                                                                int rows, float inv_d, float eps) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f, q = 0.f;
+  for (int p = 0; p < nparts; ++p) {
+    const f2 v = *reinterpret_cast<const f2*>(part + 2 * ((size_t)p * rows + r));
+    s += v[0]; q += v[1];
+  }
+  const float mean = s * inv_d;
+  const float var = fmaxf(q * inv_d - mean * mean, 0.f);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  *reinterpret_cast<f2*>(stat + 2 * (size_t)r) = f2{rstd, -rstd * mean};
+}
+
+}  // namespace
+
+// W / gamma / beta / bias / Wf / cd / N: HOST arrays of `count` (<= 32) device pointers / row counts; every matrix is [N_e][K]
+// fp16, K % 8 == 0, K <= 1024 x 8; bias entries may be NULL.  cd_e: [2][N_e] fp32 (c, then d).
+extern "C" int hmmc_ln_fold_prep(const void* const* W, const float* const* gamma, const float* const* beta, const void* const* bias,
+                                 void* const* Wf, float* const* cd, const int* N, int K, int count, hipStream_t stream) {
+  if (!W || !gamma || !beta || !bias || !Wf || !cd || !N || count <= 0 || count > PREP_MAX || K <= 0) return HMMC_ERR_ARG;
+  if (K & 7) return HMMC_ERR_UNSUPPORTED;
+  PrepArgs a{};
+  a.n = count; a.K = K;
+  int rows = 0;
+  for (int e = 0; e < count; ++e) {
+    if (!W[e] || !gamma[e] || !beta[e] || !Wf[e] || !cd[e] || N[e] <= 0) return HMMC_ERR_ARG;
+    if (((uintptr_t)W[e] | (uintptr_t)Wf[e] | (uintptr_t)gamma[e] | (uintptr_t)beta[e]) & 15) return HMMC_ERR_UNSUPPORTED;
+    a.it[e] = PrepItem{(const half_t*)W[e], gamma[e], beta[e], (const half_t*)bias[e], (half_t*)Wf[e], cd[e], N[e], rows};
+    rows += N[e];
+  }
+  a.rows = rows;
+  hipLaunchKernelGGL(ln_fold_prep_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  return hmmc_launch_status();
+}
+
+// stat[rows][2] = (rstd_r, -rstd_r mean_r) of the fp16 rows x[r * stride .. + D)
+extern "C" int hmmc_rowstat(const void* x, float* stat, int rows, int D, long stride, float eps, hipStream_t stream) {
+  if (!x || !stat || rows <= 0 || D <= 0) return HMMC_ERR_ARG;
+  if ((D & 7) || D > 1024 || (stride & 7) || (((uintptr_t)x) & 15) || (((uintptr_t)stat) & 7)) return HMMC_ERR_UNSUPPORTED;
+  const int cus = hmmc_num_cus();
+  int blocks = (rows + 3) / 4;
+  if (blocks > cus * 8) blocks = cus * 8;
+  hipLaunchKernelGGL(rowstat_kernel, dim3(blocks), dim3(256), 0, stream, (const half_t*)x, stat, rows, D, stride, eps);
+  return hmmc_launch_status();
+}
+
+// part: the [nparts][rows][2] output of a HMMC_EPI_ROWSTAT launch over rows of D = 64 nparts columns
+extern "C" int hmmc_rowstat_finalize(const float* part, float* stat, int nparts, int rows, int D, float eps, hipStream_t stream) {
+  if (!part || !stat || nparts <= 0 || rows <= 0 || D <= 0) return HMMC_ERR_ARG;
+  hipLaunchKernelGGL(rowstat_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, part, stat, nparts, rows, 1.0f / D, eps);
+  return hmmc_launch_status();
+}

@@ -417,6 +417,99 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(T* __restrict__ x, const
   }
 }
 
+// vit_embed_kernel and ln_pre in ONE pass over the patch-embed GEMM's output (fp16 tower; modules/module_clip.py:311-313): a wave
+// per row reads x0, applies the class / positional embedding with the same rounding points, optionally writes the embedded
+// row back (the backward of ln_pre needs it), normalises it in registers and writes y; `stat` (optional) receives
+// (rstd, -rstd mean) of the ROUNDED y row for the first folded GEMM of the tower (ln_fold.hip).  Saves the 240 us in-place
+// pass and the statistics pass at 153 600 x 768.  Structure of ln_fwd_kernel: next row requested before this one is reduced.
+__global__ __launch_bounds__(256) void vit_embed_ln_kernel(half_t* __restrict__ x0, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, half_t* __restrict__ y,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           float* __restrict__ stat, int rows, int L, int D, float eps,
+                                                           float stat_eps, int write_x0) {
+  constexpr int MAXV = LN_MAXD / 64 / 8;
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  const int nchunk = D / 8;
+  bool ok[MAXV];
+  int ce[MAXV];
+  float gm[MAXV][8], bt[MAXV][8], cl[MAXV][8];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    ok[i] = lane + 64 * i < nchunk;
+    ce[i] = ok[i] ? (lane + 64 * i) * 8 : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gm[i][j] = gamma[ce[i] + j]; bt[i][j] = beta[ce[i] + j]; cl[i][j] = r16(cls[ce[i] + j]); }
+  }
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  h8 cur[MAXV], nxt[MAXV];
+  f4 pc[MAXV][2], pn[MAXV][2];
+  auto load_row = [&](int r, h8 (&t)[MAXV], f4 (&pp)[MAXV][2]) {
+    const half_t* xr = x0 + (long)r * D;
+    const float* pr = pos + (long)(r % L) * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      t[i] = *reinterpret_cast<const h8*>(xr + ce[i]);
+      pp[i][0] = *reinterpret_cast<const f4*>(pr + ce[i]);
+      pp[i][1] = *reinterpret_cast<const f4*>(pr + ce[i] + 4);
+    }
+  };
+  load_row(row, cur, pc);
+  for (; row < rows; row += nwaves) {
+    load_row(min(row + nwaves, rows - 1), nxt, pn);
+    const bool is_cls = (row % L) == 0;
+    float v[MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      h8 e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = is_cls ? cl[i][j] : (float)cur[i][j];           // conv output of the zero patch row is 0
+        v[i][j] = r16(t + r16(pc[i][j >> 2][j & 3]));
+        e[j] = (half_t)v[i][j];
+        if (ok[i]) s += v[i][j];
+      }
+      if (write_x0 && ok[i]) *reinterpret_cast<h8*>(x0 + (long)row * D + ce[i]) = e;
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; if (ok[i]) q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    half_t* yr = y + (long)row * D;
+    float ys = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      h8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o[j] = (half_t)((v[i][j] - mean) * rstd * gm[i][j] + bt[i][j]);
+        v[i][j] = (float)o[j];
+        if (ok[i]) ys += v[i][j];
+      }
+      if (ok[i]) *reinterpret_cast<h8*>(yr + ce[i]) = o;
+    }
+    if (stat) {                                           // statistics of the row just written, two-pass like rowstat_kernel
+      const float ym = wave_sum(ys) / D;
+      float yq = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - ym; if (ok[i]) yq += d * d; }
+      const float yr_ = 1.0f / sqrtf(wave_sum(yq) / D + stat_eps);
+      if (lane == 0) *reinterpret_cast<f2*>(stat + 2 * (size_t)row) = f2{yr_, -yr_ * ym};
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { cur[i] = nxt[i]; pc[i][0] = pn[i][0]; pc[i][1] = pn[i][1]; }
+  }
+}
+
 // x[b][l][:] = fp16( fp16(table[ids[b][l]][:]) + fp16(pos[l][:]) )
 // ids outside [0, vocab) never index the table: the row is written as the position embedding alone and *err is set
 // (the reference's nn.Embedding raises an index error; a device kernel cannot, so the host checks the flag)
@@ -743,6 +836,22 @@ extern "C" int hmmc_vit_embed(void* x, const float* cls, const float* pos, long 
   else
     hipLaunchKernelGGL(vit_embed_kernel<float>, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, (float*)x, cls, pos,
                        rows, L, D);
+  return hmmc_launch_status();
+}
+
+// fp16 tower only.  x0: the patch-embed GEMM output [rows, D] (class rows zero), rewritten with the embedded rows when write_x0;
+// y = ln_pre(embedded) [rows, D]; mean / rstd [rows] of the embedded rows (for hmmc_layernorm_bwd); stat (optional, [rows][2]):
+// (rstd, -rstd mean) of the rows of y, the operand hmmc_tower_fwd_fused's first folded GEMM needs.
+extern "C" int hmmc_vit_embed_ln(void* x0, const float* cls, const float* pos, const float* gamma, const float* beta, void* y,
+                                 float* mean, float* rstd, float* stat, int rows, int L, int D, float eps, int write_x0,
+                                 hipStream_t stream) {
+  if (!x0 || !cls || !pos || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || L <= 0) return HMMC_ERR_ARG;
+  if (D % 8 || D > LN_MAXD) return HMMC_ERR_UNSUPPORTED;
+  int nb = (rows + 31) / 32;
+  const int cap = hmmc_num_cus() * 8;
+  if (nb > cap) nb = cap;
+  hipLaunchKernelGGL(vit_embed_ln_kernel, dim3(nb < 1 ? 1 : nb), dim3(256), 0, stream, (half_t*)x0, cls, pos, gamma, beta, (half_t*)y,
+                     mean, rstd, stat, rows, L, D, eps, eps, write_x0);
   return hmmc_launch_status();
 }
 

@@ -37,13 +37,20 @@ size_t hmmc_gemm_f16_colsum_rows(int, int, int);
 size_t hmmc_gemm_f16_wgrad_group_workspace(const int*, const int*, int, int);
 int hmmc_gemm_f16_wgrad_group(const void* const*, const void* const*, void* const*, const int*, const int*, int, int, void*, size_t,
                               hipStream_t);
+int hmmc_gemm_f16_fold(const void*, const void*, void*, int, int, int, int, int, int, const void*, const void*, int, const float*,
+                       const float*, float*, hipStream_t);
+int hmmc_ln_fold_prep(const void* const*, const float* const*, const float* const*, const void* const*, void* const*, float* const*,
+                      const int*, int, int, hipStream_t);
+int hmmc_rowstat(const void*, float*, int, int, long, float, hipStream_t);
+int hmmc_rowstat_finalize(const float*, float*, int, int, int, float, hipStream_t);
 int hmmc_temporal_attention_fwd(const float*, float*, float*, int, int, int, int, hipStream_t);
 int hmmc_temporal_attention_bwd(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
 }
 
 namespace {
 
-enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32, EPI_SAVE_DGELU = 64, EPI_MULAUX = 128 };
+enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32, EPI_SAVE_DGELU = 64, EPI_MULAUX = 128,
+       EPI_LNFOLD = 256, EPI_ROWSTAT = 512 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -234,6 +241,91 @@ extern "C" int hmmc_tower_fwd(const void* x, void* y, const void* const* params,
     // fp16 tower: the `h` slot receives QuickGELU'(pre-activation), which is all the backward needs of it
     CK(linear(f32, a.ln2, P[8], a.g, (int)T, 4 * D, D, P[9], nullptr, keep_acts ? a.h : nullptr, save_epi, workspace, ws_bytes, s));
     CK(linear(f32, a.g, P[10], out, (int)T, D, 4 * D, P[11], a.x1, nullptr, 0, workspace, ws_bytes, s));
+    cur = out;
+  }
+  return HMMC_OK;
+}
+
+// ---- forward with the LayerNorms folded into in_proj / c_fc (fp16 towers, no saved activations) ----------------------------
+// Per layer: [3D + 4D][D] fp16 folded weights + [2][3D + 4D] fp32 column terms; shared: the row pairs [T][2] and the
+// per-64-column partial statistics [D / 64][T][2] of the residual stream (see ln_fold.hip).
+namespace {
+struct FoldLayer { char *w1, *w2; float *cd1, *cd2; };
+struct FoldWs { float *stat, *part; size_t per_layer, bytes; };
+FoldWs fold_carve(char* base, long T, int D, int nlayers, FoldLayer* out) {
+  FoldWs f;
+  const size_t w1 = al((size_t)3 * D * D * 2), w2 = al((size_t)4 * D * D * 2), c1 = al((size_t)2 * 3 * D * 4), c2 = al((size_t)2 * 4 * D * 4);
+  f.per_layer = w1 + w2 + c1 + c2;
+  char* p = base;
+  for (int i = 0; i < nlayers; ++i) {
+    if (out) { out[i].w1 = p; out[i].w2 = p + w1; out[i].cd1 = (float*)(p + w1 + w2); out[i].cd2 = (float*)(p + w1 + w2 + c1); }
+    p += f.per_layer;
+  }
+  f.stat = (float*)p; p += al((size_t)T * 2 * 4);
+  f.part = (float*)p; p += al((size_t)(D / 64) * T * 2 * 4);
+  f.bytes = (size_t)(p - base);
+  return f;
+}
+}  // namespace
+
+extern "C" size_t hmmc_tower_fold_bytes(long tokens, int D, int nlayers) { return fold_carve(nullptr, tokens, D, nlayers, nullptr).bytes; }
+
+// y = tower(x) for an fp16 tower whose activations are not kept (eval, momentum encoders), ln_1 / ln_2 folded into in_proj /
+// c_fc: the same blocks as hmmc_tower_fwd (modules/module_clip.py:231-257) without the four LayerNorm passes over the
+// residual stream per layer.  acts: ONE slab of hmmc_tower_act_bytes(); fold_ws: hmmc_tower_fold_bytes(); x_stat (optional):
+// the row pairs (rstd, -rstd mean) [tokens][2] of x when its producer already has them (hmmc_vit_embed_ln).
+extern "C" int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y, const void* const* params, void* acts, int nseq, int L,
+                                    int heads, int D, int nlayers, int causal, float eps, int lead_only, void* fold_ws,
+                                    size_t fold_bytes, hipStream_t s) {
+  if (!x || !y || !params || !acts || !fold_ws || nseq <= 0 || L <= 0 || heads <= 0 || nlayers <= 0 || D != heads * 64) return HMMC_ERR_ARG;
+  const long T = (long)nseq * L;
+  if ((uint64_t)(T + 256) * 4 * D * 2 >= (1ull << 31) - (1ull << 24)) return HMMC_ERR_UNSUPPORTED;     // operands of 2 GiB: hmmc_tower_fwd
+  std::vector<FoldLayer> fl(nlayers);
+  const FoldWs fw = fold_carve((char*)fold_ws, T, D, nlayers, fl.data());
+  if (fold_bytes < fw.bytes) return HMMC_ERR_WORKSPACE;
+  // folded weights and column terms of every layer (16 layers = 32 matrices per launch)
+  for (int l0 = 0; l0 < nlayers; l0 += 16) {
+    const void* W[32]; const float* gm[32]; const float* bt[32]; const void* bs[32]; void* Wf[32]; float* cd[32]; int N[32];
+    int n = 0;
+    for (int i = l0; i < nlayers && i < l0 + 16; ++i) {
+      const void* const* P = params + (size_t)i * 12;
+      W[n] = P[2]; gm[n] = (const float*)P[0]; bt[n] = (const float*)P[1]; bs[n] = P[3]; Wf[n] = fl[i].w1; cd[n] = fl[i].cd1; N[n] = 3 * D; ++n;
+      W[n] = P[8]; gm[n] = (const float*)P[6]; bt[n] = (const float*)P[7]; bs[n] = P[9]; Wf[n] = fl[i].w2; cd[n] = fl[i].cd2; N[n] = 4 * D; ++n;
+    }
+    CK(hmmc_ln_fold_prep(W, gm, bt, bs, Wf, cd, N, D, n, s));
+  }
+  // row pairs of the tower's input: given by the kernel that produced x (hmmc_vit_embed_ln), or taken from x here
+  const float* stat0 = x_stat;
+  if (!stat0) { CK(hmmc_rowstat(x, fw.stat, (int)T, D, D, eps, s)); stat0 = fw.stat; }
+  const int nparts = D / 64;
+  const void* cur = x;
+  for (int i = 0; i < nlayers; ++i) {
+    const void* const* P = params + (size_t)i * 12;
+    Acts a = carve((char*)acts, T, D, nseq, L, heads, 2, false);
+    const void* xin = cur;
+    CK(hmmc_gemm_f16_fold(xin, fl[i].w1, a.qkv, (int)T, 3 * D, D, D, D, 3 * D, nullptr, nullptr, EPI_LNFOLD, i == 0 ? stat0 : fw.stat, fl[i].cd1,
+                          nullptr, s));
+    CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+    void* out = y;
+    if (i + 1 < nlayers) out = (void*)(((i & 1) == 0) ? a.x : a.h);
+    if (lead_only && i + 1 == nlayers) {
+      // the last block's per-token half on the leading rows only, as hmmc_tower_fwd: the same folded arithmetic on rows
+      // addressed in place at stride L*D (so a class-token row comes out bit-identical to the all-token pass)
+      const int ldl = L * D;
+      CK(hmmc_gemm_f16_fold(a.att, P[4], a.x1, nseq, D, D, ldl, D, ldl, P[5], xin, EPI_BIAS | EPI_RESID | EPI_ROWSTAT, nullptr, nullptr, fw.part, s));
+      CK(hmmc_rowstat_finalize(fw.part, fw.stat, nparts, nseq, D, eps, s));
+      CK(hmmc_gemm_f16_fold(a.x1, fl[i].w2, a.g, nseq, 4 * D, D, ldl, D, 4 * D, nullptr, nullptr, EPI_LNFOLD | EPI_QGELU, fw.stat, fl[i].cd2, nullptr, s));
+      CK(hmmc_gemm_f16(a.g, P[10], out, nseq, D, 4 * D, 4 * D, 4 * D, ldl, 1, 1, P[11], a.x1, nullptr, nullptr, EPI_BIAS | EPI_RESID, nullptr, 0, s));
+      cur = out;
+      continue;
+    }
+    CK(hmmc_gemm_f16_fold(a.att, P[4], a.x1, (int)T, D, D, D, D, D, P[5], xin, EPI_BIAS | EPI_RESID | EPI_ROWSTAT, nullptr, nullptr, fw.part, s));
+    CK(hmmc_rowstat_finalize(fw.part, fw.stat, nparts, (int)T, D, eps, s));
+    CK(hmmc_gemm_f16_fold(a.x1, fl[i].w2, a.g, (int)T, 4 * D, D, D, D, 4 * D, nullptr, nullptr, EPI_LNFOLD | EPI_QGELU, fw.stat, fl[i].cd2, nullptr, s));
+    const bool more = i + 1 < nlayers;
+    CK(hmmc_gemm_f16_fold(a.g, P[10], out, (int)T, D, 4 * D, 4 * D, 4 * D, D, P[11], a.x1, EPI_BIAS | EPI_RESID | (more ? EPI_ROWSTAT : 0), nullptr,
+                          nullptr, more ? fw.part : nullptr, s));
+    if (more) CK(hmmc_rowstat_finalize(fw.part, fw.stat, nparts, (int)T, D, eps, s));
     cur = out;
   }
   return HMMC_OK;

@@ -60,6 +60,7 @@ class Transformer(nn.Module):
         self.width, self.layers, self.heads = width, layers, heads
         self.causal = attn_mask is not None
         self.ddp_layers_per_node = 3           # world_size > 1 only: granularity of gradient hand-over to DDP
+        self.fold_ln = False                   # no-grad passes with ln_1 / ln_2 folded into the GEMMs (functional.fold_enabled)
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
 
     def flat_params(self):
@@ -68,7 +69,7 @@ class Transformer(nn.Module):
             out += Fn.block_params(blk)
         return out
 
-    def forward(self, x, nseq, L, lead_only=False):
+    def forward(self, x, nseq, L, lead_only=False, x_stat=None):
         """x: [nseq*L, width] fp16 -> same shape.  lead_only: the caller reads only token 0 of every sequence of the result
         (the class token), so the last block's per-token half runs on those rows alone; the other rows are undefined."""
         if x.dtype not in (torch.float16, torch.float32):
@@ -86,7 +87,8 @@ class Transformer(nn.Module):
             params = []
             for blk in blocks[i:i + per]:
                 params += Fn.block_params(blk)
-            x = Fn.ClipTransformerFn.apply(x, nseq, L, self.heads, self.causal, bool(lead_only and i + per >= self.layers), *params)
+            x = Fn.clip_transformer(x, nseq, L, self.heads, self.causal, bool(lead_only and i + per >= self.layers), *params,
+                                    x_stat=x_stat if i == 0 else None, fold=Fn.fold_enabled(self.fold_ln))
         return x
 
 
@@ -103,6 +105,7 @@ class VisualTransformer(nn.Module):
         self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
         self.ln_pre = LayerNorm(width)
         self.transformer = Transformer(width, layers, heads)
+        self.transformer.fold_ln = True
         self.ln_post = LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
         self.linear_patch = linear_patch
@@ -121,9 +124,9 @@ class VisualTransformer(nn.Module):
         n = x.shape[0] if frame_index is None else frame_index.numel()
         # the kernel casts fp32 pixels to fp16 while patchifying (image.type(fp16)); raw uint8 frames are normalised there too
         x = x.contiguous() if x.dtype == torch.uint8 else x.float().contiguous()
-        t = Fn.VitEmbedFn.apply(x, self.conv1.weight, self.class_embedding, self.positional_embedding,
-                                self.ln_pre.weight, self.ln_pre.bias, frame_index)
-        return self.transformer(t, n, self.tokens, lead_only)
+        t, stat = Fn.vit_embed(x, self.conv1.weight, self.class_embedding, self.positional_embedding,
+                               self.ln_pre.weight, self.ln_pre.bias, frame_index)
+        return self.transformer(t, n, self.tokens, lead_only, x_stat=stat)
 
 
 def convert_weights(model: nn.Module):

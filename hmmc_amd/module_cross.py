@@ -129,11 +129,11 @@ class VisualEncoder(nn.Module):
         if self.use_temp:
             if frames > self.frame_position_embeddings.weight.shape[0]:
                 raise ValueError("more frames than max_position_embeddings")
-            visual_output = Fn.TemporalFn.apply(frame_output, self.temporal_transformer.heads,
+            visual_output = Fn.temporal(frame_output, self.temporal_transformer.heads,
                                                 self.frame_position_embeddings.weight,
                                                 *self.temporal_transformer.flat_params())
         else:
-            visual_output = Fn.TemporalFn.apply(frame_output, 0, None)
+            visual_output = Fn.temporal(frame_output, 0, None)
         return visual_output, frame_output
 
     def encode_image(self, image, return_hidden=False, video_frame=-1, frame_index=None):

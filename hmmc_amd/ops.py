@@ -14,6 +14,7 @@ from ._lib import call, ptr, query
 EPI_BIAS, EPI_RESID, EPI_QGELU, EPI_DGELU = 1, 2, 4, 8
 EPI_COLSUM = 32
 EPI_SAVE_DGELU, EPI_MULAUX = 64, 128
+EPI_LNFOLD, EPI_ROWSTAT = 256, 512
 
 _ws_cache = {}
 
@@ -115,6 +116,69 @@ def gemm_f16(a, b, M, N, K, a_kmajor=True, b_kmajor=True, bias=None, resid=None,
     call("hmmc_gemm_f16", ptr(a), ptr(b), ptr(c), M, N, K, a.shape[1], b.shape[1], N, int(a_kmajor), int(b_kmajor),
          ptr(bias), ptr(resid), ptr(aux_out), ptr(aux_in), epilogue, ptr(ws), wsb)
     return (c, aux_out) if want_aux else c
+
+
+def ln_fold_prep(items):
+    """items: [(W [N,K] fp16, gamma [K] fp32, beta [K] fp32, bias [N] fp16 or None)] -> [(gamma o W fp16, cd [2,N] fp32)]:
+    the operands of a GEMM with the LayerNorm in front of it folded in (include/hmmc_hip.h, hmmc_ln_fold_prep)."""
+    import ctypes
+    n = len(items)
+    K = items[0][0].shape[1]
+    outs = []
+    for W, gm, bt, bias in items:
+        _chk(W, torch.float16, "W"); _chk(gm, torch.float32, "gamma"); _chk(bt, torch.float32, "beta")
+        assert W.shape[1] == K and gm.numel() == K and bt.numel() == K
+        if bias is not None:
+            _chk(bias, torch.float16, "bias")
+        outs.append((torch.empty_like(W), torch.empty((2, W.shape[0]), dtype=torch.float32, device=W.device)))
+    P = ctypes.c_void_p * n
+    pa = lambda ts: P(*[None if t is None else t.data_ptr() for t in ts])
+    call("hmmc_ln_fold_prep", pa([i[0] for i in items]), pa([i[1] for i in items]), pa([i[2] for i in items]), pa([i[3] for i in items]),
+         pa([o[0] for o in outs]), pa([o[1] for o in outs]), (ctypes.c_int * n)(*[i[0].shape[0] for i in items]), K, n)
+    return outs
+
+
+def rowstat(x):
+    """[rows, 2] fp32 = (rstd_r, -rstd_r mean_r) of fp16 rows (eps 1e-5: the CLIP LayerNorm)."""
+    _chk(x, torch.float16, "x")
+    rows, D = x.shape
+    out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    call("hmmc_rowstat", ptr(x), ptr(out), rows, D, D, 1e-5)
+    return out
+
+
+def rowstat_finalize(part, D):
+    """part [D / 64, rows, 2] (sum, sum of squares) from an EPI_ROWSTAT launch -> [rows, 2] as rowstat()."""
+    _chk(part, torch.float32, "part")
+    nparts, rows, _ = part.shape
+    out = torch.empty((rows, 2), dtype=torch.float32, device=part.device)
+    call("hmmc_rowstat_finalize", ptr(part), ptr(out), nparts, rows, D, 1e-5)
+    return out
+
+
+def gemm_f16_fold(a, b, bias=None, resid=None, epilogue=0, rowstat=None, colterms=None, want_stat=False, out=None):
+    """C = epi(a[M,K] b[N,K]^T) with a LayerNorm folded in (EPI_LNFOLD: rowstat [M,2], colterms [2,N]) and / or the row
+    statistics of C emitted per 64-column block (want_stat -> second result [N/64, M, 2])."""
+    _chk(a, torch.float16, "a"); _chk(b, torch.float16, "b")
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    c = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=a.device)
+    if bias is not None:
+        _chk(bias, torch.float16, "bias"); epilogue |= EPI_BIAS
+    if resid is not None:
+        _chk(resid, torch.float16, "resid"); assert tuple(resid.shape) == (M, N); epilogue |= EPI_RESID
+    if rowstat is not None:
+        _chk(rowstat, torch.float32, "rowstat"); _chk(colterms, torch.float32, "colterms")
+        assert tuple(rowstat.shape) == (M, 2) and tuple(colterms.shape) == (2, N)
+        epilogue |= EPI_LNFOLD
+    part = None
+    if want_stat:
+        part = torch.empty((N // 64, M, 2), dtype=torch.float32, device=a.device)
+        epilogue |= EPI_ROWSTAT
+    call("hmmc_gemm_f16_fold", ptr(a), ptr(b), ptr(c), M, N, K, K, K, N, ptr(bias), ptr(resid), epilogue, ptr(rowstat), ptr(colterms),
+         ptr(part))
+    return (c, part) if want_stat else c
 
 
 def wgrad_group(dys, xs):
@@ -243,6 +307,20 @@ def vit_embed_(x, cls, pos, L):
     _chk(pos, torch.float32, "pos")
     call("hmmc_vit_embed", ptr(x), ptr(cls), ptr(pos), x.shape[0], L, x.shape[1], _dt(x.dtype))
     return x
+
+
+def vit_embed_ln_(x0, cls, pos, gamma, beta, L, want_stat=False, write_x0=True):
+    """vit_embed_ + layernorm_fwd(eps 1e-5) in one pass (fp16): x0 is rewritten with the embedded rows when write_x0.
+    -> (y, mean, rstd, stat or None); stat [rows, 2] = (rstd, -rstd mean) of the rows of y."""
+    _chk(x0, torch.float16, "x0")
+    rows, D = x0.shape
+    y = torch.empty_like(x0)
+    mean = torch.empty(rows, dtype=torch.float32, device=x0.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x0.device)
+    stat = torch.empty((rows, 2), dtype=torch.float32, device=x0.device) if want_stat else None
+    call("hmmc_vit_embed_ln", ptr(x0), ptr(cls), ptr(pos), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), ptr(stat), rows, L, D,
+         1e-5, int(write_x0))
+    return y, mean, rstd, stat
 
 
 def text_embed(ids, table, pos, dtype=torch.float16):

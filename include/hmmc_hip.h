@@ -43,6 +43,8 @@ typedef void* hmmc_stream_t; /* hipStream_t */
 #define HMMC_EPI_SAVE_DGELU 64 /* with QGELU: aux_out = QuickGELU'(h) instead of h (what the backward multiplies by) */
 #define HMMC_EPI_MULAUX 128 /* out = acc * aux_in (backward of QuickGELU with the saved derivative)        */
 #define HMMC_EPI_COLSUM 32 /* + fp32 partial column sums of C into `workspace` (see hmmc_gemm_f16_colsum_rows) */
+#define HMMC_EPI_LNFOLD 256  /* hmmc_gemm_f16_fold: acc -> rowstat[m][0] * acc + rowstat[m][1] * colterms[n] + colterms[N + n] */
+#define HMMC_EPI_ROWSTAT 512 /* hmmc_gemm_f16_fold: + (sum, sum of squares) of every output row per 64-column block into stat_part */
 
 /* fp16 MFMA GEMM, fp32 accumulate: C[M,N] = epilogue(sum_k Aop[m][k] * Bop[n][k]).
  * a_kmajor: Aop[m][k] = A[m*lda + k], else A[k*lda + m]; likewise b_kmajor for B (rows n).
@@ -77,6 +79,25 @@ int hmmc_gemm_reserve_cus(int cus);
 int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor,
                   int b_kmajor, const void* bias, const void* resid, void* aux_out, const void* aux_in, int epilogue,
                   void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+
+/* LayerNorm folded into the linear layer behind it (fp16 towers; ln_1 -> in_proj and ln_2 -> c_fc of ResidualAttentionBlock,
+ * modules/module_clip.py:252-256 with the LayerNorm of :217-223):
+ *   LN(x) W^T + b = rstd_r (x (gamma o W)^T)[r][n] - rstd_r mean_r c_n + d_n,  c_n = sum_k (gamma o W)[n][k],  d_n = sum_k beta_k W[n][k] + b_n
+ * so the GEMM reads the raw residual stream and LN(x) never exists in memory.  hmmc_ln_fold_prep writes gamma o W (fp16, one
+ * rounding), c (sums of the rounded values) and d for `count` <= 32 weight matrices [N_e][K] in one launch (W / gamma / beta /
+ * bias / Wf / cd / N are HOST arrays; cd_e is [2][N_e] fp32: c, then d; bias entries may be NULL).  hmmc_rowstat gives the row
+ * pairs (rstd_r, -rstd_r mean_r) [rows][2] of fp16 rows; hmmc_rowstat_finalize gives the same from the partial sums a
+ * HMMC_EPI_ROWSTAT launch wrote ([nparts = D / 64][rows][2]).  hmmc_gemm_f16_fold is hmmc_gemm_f16 for k-major operands with
+ * those operands: HMMC_EPI_LNFOLD (needs rowstat, colterms; bias is inside d) optionally with HMMC_EPI_QGELU; HMMC_EPI_ROWSTAT
+ * (needs stat_part, N % 64 == 0) with any of BIAS / RESID.  The rounding points differ from LayerNorm-then-GEMM (gamma o W is
+ * rounded instead of LN(x)): hmmc_tower_fwd_fused uses this for forward passes that keep no activations. */
+int hmmc_ln_fold_prep(const void* const* W, const float* const* gamma, const float* const* beta, const void* const* bias,
+                      void* const* Wf, float* const* cd, const int* N, int K, int count, hmmc_stream_t stream);
+int hmmc_rowstat(const void* x, float* stat, int rows, int D, long stride, float eps, hmmc_stream_t stream);
+int hmmc_rowstat_finalize(const float* part, float* stat, int nparts, int rows, int D, float eps, hmmc_stream_t stream);
+int hmmc_gemm_f16_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, const void* bias,
+                       const void* resid, int epilogue, const float* rowstat, const float* colterms, float* stat_part,
+                       hmmc_stream_t stream);
 
 /* LayerNorm over the last dim (fp32 statistics).  dtype 0: fp16 in/out (CLIP LayerNorm,
  * modules/module_clip.py:217-223, eps 1e-5); dtype 1: fp32 (TF-style LN of the temporal blocks and
@@ -124,6 +145,12 @@ int hmmc_patchify_u8(const void* img, const int* frame_index, void* out, int nfr
 /* In place on the patch-GEMM output: class_embedding into row 0, + positional_embedding
  * (modules/module_clip.py:311-312), with the reference's fp16 rounding points (dtype 0) or in fp32 (dtype 1). */
 int hmmc_vit_embed(void* x, const float* cls, const float* pos, long rows, int L, int D, int dtype, hmmc_stream_t stream);
+/* hmmc_vit_embed and ln_pre (modules/module_clip.py:311-313) in one pass, fp16 tower: x0 [rows, D] is the patch-GEMM output and
+ * is rewritten with the embedded rows when write_x0 (the backward of ln_pre reads them); y = ln_pre(embedded rows); mean / rstd
+ * [rows] as hmmc_layernorm_fwd saves them; stat (may be NULL) [rows][2] = (rstd, -rstd mean) of the rows of y for
+ * hmmc_tower_fwd_fused.  Results are bit-identical to hmmc_vit_embed followed by hmmc_layernorm_fwd. */
+int hmmc_vit_embed_ln(void* x0, const float* cls, const float* pos, const float* gamma, const float* beta, void* y, float* mean,
+                      float* rstd, float* stat, int rows, int L, int D, float eps, int write_x0, hmmc_stream_t stream);
 /* token_embedding(ids).half() + positional_embedding[:L].half() (modules/module_cross.py:288-291).  An id outside
  * [0, vocab) never indexes the table (the reference's nn.Embedding raises): its row is the position embedding alone and
  * *err_flag (device int, may be NULL) is set to 1 for the host to check. */
@@ -287,6 +314,14 @@ size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32, int bw
 int hmmc_tower_fwd(const void* x, void* y, const void* const* params, void* acts, int keep_acts, int nseq, int L, int heads,
                    int D, int nlayers, int causal, float eps, int fp32, int lead_only, void* workspace, size_t ws_bytes,
                    hmmc_stream_t stream);
+/* hmmc_tower_fwd for an fp16 tower whose activations are not kept (eval, the momentum encoders of modules/modeling.py:347-357),
+ * with ln_1 / ln_2 folded into in_proj / c_fc (hmmc_gemm_f16_fold above): no LayerNorm pass over the residual stream, the row
+ * statistics come out of the out_proj / c_proj epilogues.  acts: ONE slab of hmmc_tower_act_bytes(); fold_ws:
+ * hmmc_tower_fold_bytes(); x_stat (may be NULL): the row pairs of x as hmmc_rowstat / hmmc_vit_embed_ln give them.  Returns HMMC_ERR_UNSUPPORTED for operands of 2 GiB and more (use hmmc_tower_fwd). */
+size_t hmmc_tower_fold_bytes(long tokens, int D, int nlayers);
+int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y, const void* const* params, void* acts, int nseq, int L,
+                         int heads, int D, int nlayers, int causal, float eps, int lead_only, void* fold_ws, size_t fold_bytes,
+                         hmmc_stream_t stream);
 /* wgrad_stream (optional, NULL = `stream`): a second stream for the weight-gradient GEMMs, which are leaves of the backward
  * pass; they then run beside the dgrad / LayerNorm / attention chain.  `stream` waits for it before the call's work is
  * complete in stream order, so callers keep single-stream semantics. */

@@ -285,13 +285,19 @@ def test_envelope_at_true_vit_b32_dims():
         sv, fk = model.eval_scores(q, v, u, top_frames=k)
         loss = model(ids, mask, vid, vf, idx, 1)
     got = {"text_feat": q, "video_emb": v, "frame_output": u, "S_video": sv, "S_frame_topk": fk}
+    fails = []
     for key, mine in got.items():
         mine = mine.cpu().numpy()
         own_max, own_l2 = float(np.abs(ga[key] - gf[key]).max()), float(np.linalg.norm(ga[key] - gf[key]) / np.linalg.norm(gf[key]))
         my_max, my_l2 = float(np.abs(mine - ga[key]).max()), float(np.linalg.norm(mine - ga[key]) / np.linalg.norm(ga[key]))
-        print(f"{key}: max |HIP - as-written| {my_max:.3e} (reference regimes {own_max:.3e}), rel-L2 {my_l2:.3e} ({own_l2:.3e})")
-        assert my_max <= ENVELOPE * own_max, f"{key}: max abs {my_max:.3e} > {ENVELOPE} x {own_max:.3e}"
-        assert my_l2 <= ENVELOPE * own_l2, f"{key}: rel-L2 {my_l2:.3e} > {ENVELOPE} x {own_l2:.3e}"
+        f32_max, f32_l2 = float(np.abs(mine - gf[key]).max()), float(np.linalg.norm(mine - gf[key]) / np.linalg.norm(gf[key]))
+        print(f"{key}: max |HIP - as-written| {my_max:.3e} (reference regimes {own_max:.3e}), rel-L2 {my_l2:.3e} ({own_l2:.3e}); "
+              f"against the reference's fp32 regime max {f32_max:.3e}, rel-L2 {f32_l2:.3e}")
+        if my_max > ENVELOPE * own_max:
+            fails.append(f"{key}: max abs {my_max:.3e} > {ENVELOPE} x {own_max:.3e}")
+        if my_l2 > ENVELOPE * own_l2:
+            fails.append(f"{key}: rel-L2 {my_l2:.3e} > {ENVELOPE} x {own_l2:.3e}")
+    assert not fails, fails
     assert abs(float(loss) - float(ga["loss"])) <= ENVELOPE * max(abs(float(ga["loss"]) - float(gf["loss"])), 1e-3)
     for key in ("S_video", "S_frame_topk"):
         mine, ra = got[key].cpu().numpy(), ga[key]
