@@ -243,6 +243,7 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
   constexpr int HB = MT > 4 ? 4 : MT;            // strips whose operand loads are in flight together (32 VGPRs)
   u4 rin[HB][2];
   const bool two = (flags & EPI_QGELU) && p.aux_out;
+  float st1[MT], st2[MT];                        // EPI_ROWSTAT: per strip, this lane's part of its row's sum and sum of squares
   f4 csum[4];                                    // EPI_COLSUM: column sums of the fp16 values written, over this wave's rows
 #pragma unroll
   for (int j = 0; j < 4; ++j) csum[j] = f4{0.f, 0.f, 0.f, 0.f};
@@ -384,18 +385,23 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
         for (int j = 0; j < 4; ++j) csum[j] += unpack2(pc[j][0], pc[j][1]);
       }
     }
-    if (flags & EPI_ROWSTAT) {
-      // this lane's 16 columns of the row -> the row's 64-column block: the other columns sit in lanes c + 16, c + 32, c + 48
-      float s1 = rs1, s2 = rs2;
-      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-      const int m = m_base + 16 * i + c;
-      if (g == 0 && (FULL || (m < p.M && n0 < p.N))) *reinterpret_cast<f2*>(p.stat_part + 2 * ((size_t)(n0 >> 6) * p.M + m)) = f2{s1, s2};
-    }
+    if (flags & EPI_ROWSTAT) { st1[i] = rs1; st2[i] = rs2; }
     store_strip(p.C, i, pc);
     if (two) store_strip(p.aux_out, i, qc);      // the pre-activation or QuickGELU'(h), for the backward pass
   }
   flush();
+  if (flags & EPI_ROWSTAT) {
+    // this lane's 16 columns of each of its MT rows -> the row's 64-column block: the other columns sit in lanes c + 16, c + 32,
+    // c + 48.  Reduced here, after the strips: inside the strip loop the shuffles (ds_bpermute) would sit in the in-order LDS
+    // queue between the tile writes and reads the loop keeps in flight, and their results would be waited for per strip.
+    auto xsum = [](float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); };
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const float s1 = xsum(st1[i]), s2 = xsum(st2[i]);
+      const int m = m_base + 16 * i + c;
+      if (g == 0 && (FULL || (m < p.M && n0 < p.N))) *reinterpret_cast<f2*>(p.stat_part + 2 * ((size_t)(n0 >> 6) * p.M + m)) = f2{s1, s2};
+    }
+  }
   if (want_csum) {                               // 16 lanes c -> one partial row per wave: row block (m_base / (16 MT))
     float* dst = p.csum + (size_t)(m_base / (16 * MT)) * p.N + n0;
 #pragma unroll
