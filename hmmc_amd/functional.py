@@ -60,16 +60,18 @@ def _wgrad(dy, x):
 # The im2col of a step's frames depends on the frames alone.  The pre-training model encodes the SAME frames with the online and
 # the momentum tower (reference modules/modeling.py:347,356): inside `share_patches()` the second VitEmbedFn call on the same
 # tensor (same storage, version, stream, patch size and dtype) takes the first one's patch matrix instead of re-reading the video.
-_PATCH_SHARE = {"on": False, "key": None, "val": None}
+# `ref` keeps the keyed frames alive while their patches are shared, so the caching allocator cannot hand the same address to a
+# different batch inside the window.
+_PATCH_SHARE = {"on": False, "key": None, "val": None, "ref": None}
 
 
 class share_patches:
     def __enter__(self):
-        _PATCH_SHARE.update(on=True, key=None, val=None)
+        _PATCH_SHARE.update(on=True, key=None, val=None, ref=None)
         return self
 
     def __exit__(self, *exc):
-        _PATCH_SHARE.update(on=False, key=None, val=None)
+        _PATCH_SHARE.update(on=False, key=None, val=None, ref=None)
         return False
 
 
@@ -88,7 +90,7 @@ def _patches_of(video4d, p, dtype, frame_index):
             raise TypeError("frame sampling on the device takes the stored uint8 frames")
         patches = ops.patchify(video4d, p, dtype=dtype)
     if key is not None:
-        _PATCH_SHARE.update(key=key, val=patches)
+        _PATCH_SHARE.update(key=key, val=patches, ref=video4d)
     return patches
 
 
@@ -555,3 +557,58 @@ class MlmHeadFn(torch.autograd.Function):
         # unused slots (zero gradient: their label is -100) all land in the dump row n
         dx = dx_rows.new_zeros(n + 1, ctx.shape[-1]).index_copy_(0, rows, dx_rows)[:n]
         return dx.view(ctx.shape), None, d_dw, d_db, d_lnw, d_lnb, d_decw, d_decb, None
+
+
+class LmLogitsFn(torch.autograd.Function):
+    """BertLMPredictionHead.forward as a differentiable op (reference modules/module_cross.py:308-357): logits =
+    decoder(TF-LayerNorm(erf-GELU(dense(x)))) + bias for EVERY row.  The training step does not come this way (MlmHeadFn
+    evaluates the head on the labelled rows only and never hands the logits out); this is the module's own call surface."""
+
+    @staticmethod
+    def forward(ctx, hidden, dw, db, lnw, lnb, decw, decb):
+        x = hidden.contiguous().view(-1, hidden.shape[-1])
+        a = ops.linear_f32(x, dw, bias=db)
+        g = ops.gelu_erf_fwd(a)
+        t, mean, rstd = ops.layernorm_fwd(g, lnw, lnb, 1e-12)
+        logits = ops.linear_f32(t, decw, bias=decb)
+        ctx.save_for_backward(x, dw, lnw, decw, a, g, t, mean, rstd)
+        ctx.shape = hidden.shape
+        return logits.view(*hidden.shape[:-1], decw.shape[0])
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x, dw, lnw, decw, a, g, t, mean, rstd = ctx.saved_tensors
+        dl = dlogits.contiguous().view(-1, decw.shape[0])
+        d_decw = ops.wgrad_f32(dl, t)
+        d_decb = ops.colsum(dl)
+        dt = ops.dgrad_f32(dl, decw)
+        dg, d_lnw, d_lnb = ops.layernorm_bwd(dt, g, lnw, mean, rstd)
+        da = ops.gelu_erf_bwd(a, dg)
+        d_dw = ops.wgrad_f32(da, x)
+        d_db = ops.colsum(da)
+        dx = ops.dgrad_f32(da, dw)
+        return dx.view(ctx.shape), d_dw, d_db, d_lnw, d_lnb, d_decw, d_decb
+
+
+class LooseSimFn(torch.autograd.Function):
+    """scale * normalise(q) normalise(v)^T, differentiable in both operands (reference modules/modeling.py:207-229).  The
+    training heads do not come this way (FinetuneHeadFn fuses the similarity with the InfoNCE terms)."""
+
+    @staticmethod
+    def forward(ctx, q, v, scale):
+        q, v = q.contiguous(), v.contiguous()
+        E = q.shape[-1]
+        qn, qnorm = ops.l2norm_fwd(q)
+        vn, vnorm = ops.l2norm_fwd(v)
+        ctx.save_for_backward(qn, qnorm, vn, vnorm)
+        ctx.scale = scale
+        return ops.gemm_f32(qn, vn, qn.shape[0], vn.shape[0], E, (E, 1), (1, E), alpha=scale)
+
+    @staticmethod
+    def backward(ctx, dS):
+        qn, qnorm, vn, vnorm = ctx.saved_tensors
+        dS = dS.contiguous()
+        nq, nv, E = qn.shape[0], vn.shape[0], qn.shape[1]
+        dqn = ops.gemm_f32(dS, vn, nq, E, nv, (nv, 1), (E, 1), alpha=ctx.scale)          # dS @ vn
+        dvn = ops.gemm_f32(dS, qn, nv, E, nq, (1, nv), (E, 1), alpha=ctx.scale)          # dS^T @ qn
+        return ops.l2norm_bwd(dqn, qn, qnorm), ops.l2norm_bwd(dvn, vn, vnorm), None

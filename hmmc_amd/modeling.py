@@ -205,16 +205,9 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
         self._queue_ptr_host = (ptr_ + B) % self.contrast_num_negative
         self.queue_ptr.fill_(self._queue_ptr_host)
 
-    # ---- MLP with train-mode BatchNorm (batch statistics shared over ranks)
+    # ---- MLP with train-mode BatchNorm (batch statistics shared over ranks): MLP.forward below
     def _mlp(self, mlp, x):
-        lin1, bn, lin2 = mlp.linear_hidden[1], mlp.linear_hidden[2], mlp.linear_out
-        out, mean, var, n = Fn.MlpFn.apply(x, lin1.weight, lin1.bias, bn.weight, bn.bias, lin2.weight, lin2.bias, bn.eps)
-        with torch.no_grad():
-            mom = bn.momentum
-            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(var * (n / (n - 1).clamp(min=1.0)), alpha=mom)
-            bn.num_batches_tracked += 1
-        return out
+        return mlp(x)
 
     # ---- losses
     def contrastive_loss(self, q, k, queue):
@@ -327,28 +320,29 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
                 t.record_stream(side)
             with torch.cuda.stream(side):
                 tag_fea, title_fea, mlm_hidden = online_text()
-        share = Fn.share_patches()                      # the momentum tower below encodes the same frames: one im2col for both
-        share.__enter__()
-        v_fea, frame_fea = self.visual_encoder(video, video_frame)
-        if not overlap:
-            tag_fea, title_fea, mlm_hidden = online_text()
-        bs, frame, hidden = frame_fea.shape
-        frame_proj = self._mlp(self.v_projector, frame_fea.reshape(-1, hidden))
-        frame_pred = self._mlp(self.v_predictor, frame_proj).view(bs, frame, hidden)
-        frame_proj = frame_proj.view(bs, frame, hidden)
-        with torch.no_grad():
-            self._momentum_update()
-            if overlap:
-                ema_done = torch.cuda.Event()
-                ema_done.record(cur)
-                side.wait_event(ema_done)
-                with torch.cuda.stream(side):
+        # the momentum tower below encodes the same frames: one im2col for both (the context manager drops the shared patch
+        # matrix on every exit path, so a failed step cannot leave a stale one behind for the next caller)
+        with Fn.share_patches():
+            v_fea, frame_fea = self.visual_encoder(video, video_frame)
+            if not overlap:
+                tag_fea, title_fea, mlm_hidden = online_text()
+            bs, frame, hidden = frame_fea.shape
+            frame_proj = self.v_projector(frame_fea.reshape(-1, hidden))
+            frame_pred = self.v_predictor(frame_proj).view(bs, frame, hidden)
+            frame_proj = frame_proj.view(bs, frame, hidden)
+            with torch.no_grad():
+                self._momentum_update()
+                if overlap:
+                    ema_done = torch.cuda.Event()
+                    ema_done.record(cur)
+                    side.wait_event(ema_done)
+                    with torch.cuda.stream(side):
+                        tag_fea_k, title_fea_k = key_text()
+                else:
                     tag_fea_k, title_fea_k = key_text()
-            else:
-                tag_fea_k, title_fea_k = key_text()
-            v_fea_k, frame_fea_k = self.visual_encoder_k(video, video_frame)
-            share.__exit__(None, None, None)
-            frame_proj_k = self._mlp(self.v_projector_k, frame_fea_k.reshape(-1, hidden)).view(bs, frame, hidden)
+                v_fea_k, frame_fea_k = self.visual_encoder_k(video, video_frame)
+        with torch.no_grad():
+            frame_proj_k = self.v_projector_k(frame_fea_k.reshape(-1, hidden)).view(bs, frame, hidden)
         if overlap:
             cur.wait_stream(side)
             for t in (tag_fea, title_fea, tag_fea_k, title_fea_k, mlm_hidden):
@@ -392,14 +386,15 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
 
     def loose_similarity(self, sequence_output, visual_output):
         """100 * n(q) n(v)^T; visual may be [bv,512] or [bv,F,512] -> [bq,bv,F]
-        (reference modules/modeling.py:207-229).  Inference-only entry point (eval scorer); training
-        goes through the fused InfoNCE head."""
-        if torch.is_grad_enabled() and (sequence_output.requires_grad or visual_output.requires_grad):
-            raise RuntimeError("loose_similarity is the eval entry point; training uses the fused InfoNCE head")
+        (reference modules/modeling.py:207-229).  Differentiable when its inputs require grad; the training step itself goes
+        through the fused InfoNCE head."""
         q = sequence_output.contiguous().float().view(-1, sequence_output.shape[-1])
         v = visual_output.contiguous().float()
         E = q.shape[-1]
         scale = min(math.exp(float(self.text_encoder.logit_scale)), 100.0)
+        if torch.is_grad_enabled() and (q.requires_grad or v.requires_grad):      # differentiable, as the reference's
+            S = Fn.LooseSimFn.apply(q, v.view(-1, E), scale)
+            return S.view(q.shape[0], v.shape[0], v.shape[1]) if v.dim() == 3 else S
         qn, _ = ops.l2norm_fwd(q)
         three_d = v.dim() == 3
         vn, _ = ops.l2norm_fwd(v.view(-1, E))
@@ -532,3 +527,28 @@ class MLP(nn.Module):
             hidden.append(nn.ReLU(inplace=True))
         self.linear_hidden = nn.Sequential(*hidden)
         self.linear_out = nn.Linear(in_dim if num_layers == 1 else inner_dim, out_dim) if num_layers >= 1 else nn.Identity()
+        self.num_layers = num_layers
+
+    def forward(self, x):
+        """linear_out(linear_hidden(x)) (reference modules/modeling.py:803-807) on the fused kernels: Linear -> BatchNorm1d ->
+        ReLU -> Linear in one autograd node.  Training mode: batch statistics over every rank's rows (the reference converts
+        the model to SyncBatchNorm, main_pretrain.py:199-204) and the running statistics are updated as nn.BatchNorm1d does;
+        eval mode: the running statistics, forward only."""
+        if self.num_layers != 2:
+            raise NotImplementedError("the HMMC projector / predictor MLPs have two layers (proj_num_layers = pred_num_layers = 2)")
+        lin1, bn, lin2 = self.linear_hidden[1], self.linear_hidden[2], self.linear_out
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1]).float()
+        if not self.training:
+            if torch.is_grad_enabled() and (x.requires_grad or lin1.weight.requires_grad):
+                raise RuntimeError("MLP in eval mode is forward-only here: call it under torch.no_grad()")
+            h = ops.linear_f32(x2.contiguous(), lin1.weight, bias=lin1.bias)
+            y = ops.bn_apply_relu(h, bn.running_mean, torch.rsqrt(bn.running_var + bn.eps), bn.weight, bn.bias)
+            return ops.linear_f32(y, lin2.weight, bias=lin2.bias).view(*lead, -1)
+        out, mean, var, n = Fn.MlpFn.apply(x2, lin1.weight, lin1.bias, bn.weight, bn.bias, lin2.weight, lin2.bias, bn.eps)
+        with torch.no_grad():
+            mom = bn.momentum
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var * (n / (n - 1).clamp(min=1.0)), alpha=mom)
+            bn.num_batches_tracked += 1
+        return out.view(*lead, -1)

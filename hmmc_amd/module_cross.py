@@ -248,3 +248,10 @@ class BertLMPredictionHead(nn.Module):
         self.decoder = nn.Linear(hidden_size, vocab_size, bias=False)
         self.bias = nn.Parameter(torch.zeros(vocab_size))
         self.decoder.bias = self.bias
+
+    def forward(self, hidden_states):
+        """[..., hidden] -> [..., vocab] fp32 logits, differentiable (reference modules/module_cross.py:319-322).  The
+        pre-training loss does not call this: calculate_mlm_loss evaluates head + cross-entropy on the labelled rows only."""
+        t = self.transform
+        return Fn.LmLogitsFn.apply(hidden_states.float(), t.dense.weight, t.dense.bias, t.LayerNorm.weight, t.LayerNorm.bias,
+                                   self.decoder.weight, self.bias)

@@ -481,6 +481,58 @@ def fx_moco(mclip, mmodel, mopt, mmetrics):
         save(f"moco_{mode}", **out)
 
 
+def fx_modules(mclip, mmodel, mopt, mmetrics):
+    """The callable members of the pre-training model on their own (round 4): MLP.forward in train and eval mode
+    (modules/modeling.py:788-807), BertLMPredictionHead.forward (modules/module_cross.py:308-322) and loose_similarity with
+    gradients (modules/modeling.py:207-229), fp32 regime, seeded inputs."""
+    dims = synth.TINY
+    K, Fr = 16, 4
+    sd = synth.pretrain_state(dims, K, Fr)
+    model, cfg = build_reference_model(mclip, mmodel.BirdPreTrainedModel, dims, sd, "fp32", contrast_num_negative=K, max_frames=Fr,
+                                       dataset="chvtt")
+    out = {}
+    # MLP: two train-mode calls (batch statistics, running statistics updated), then eval mode on other rows
+    mlp = model.v_projector
+    x = synth.normal("modules.mlp.x", (24, 512)).requires_grad_()
+    w = synth.normal("modules.mlp.w", (24, 512))
+    y = mlp(x)
+    (y * w).sum().backward()
+    out["mlp_y"], out["mlp_dx"] = y, x.grad
+    out["mlp_dw1"] = mlp.linear_hidden[1].weight.grad[:8, :16]
+    out["mlp_dgamma"], out["mlp_dbeta"] = mlp.linear_hidden[2].weight.grad[:64], mlp.linear_hidden[2].bias.grad[:64]
+    out["mlp_dw2"], out["mlp_db2"] = mlp.linear_out.weight.grad[:8, :16], mlp.linear_out.bias.grad[:64]
+    out["mlp_running_mean1"], out["mlp_running_var1"] = mlp.linear_hidden[2].running_mean[:64].clone(), mlp.linear_hidden[2].running_var[:64].clone()
+    x3 = synth.normal("modules.mlp.x3", (3, 8, 512))
+    with torch.no_grad():
+        out["mlp_y3"] = mlp(x3.reshape(-1, 512)).view(3, 8, 512)
+    out["mlp_running_mean2"], out["mlp_running_var2"] = mlp.linear_hidden[2].running_mean[:64].clone(), mlp.linear_hidden[2].running_var[:64].clone()
+    mlp.eval()
+    xe = synth.normal("modules.mlp.xe", (10, 512))
+    with torch.no_grad():
+        out["mlp_y_eval"] = mlp(xe)
+    mlp.train()
+    # MLM head logits
+    h = synth.normal("modules.lm.h", (3, 7, 512)).requires_grad_()
+    wl = synth.normal("modules.lm.w", (3, 7, 64))
+    logits = model.cls(h)
+    (logits[..., :64] * wl).sum().backward()
+    out["lm_logits_head"], out["lm_logits_rowsum"] = logits[..., :128], logits.sum(-1)
+    out["lm_dh"] = h.grad
+    out["lm_ddense"] = model.cls.transform.dense.weight.grad[:8, :16]
+    out["lm_dln"] = model.cls.transform.LayerNorm.weight.grad[:64]
+    out["lm_ddec"] = model.cls.decoder.weight.grad[:8, :16]
+    out["lm_dbias"] = model.cls.bias.grad[:128]
+    # loose_similarity, differentiable, 2-D and 3-D candidates
+    q = synth.normal("modules.sim.q", (6, 512)).requires_grad_()
+    v = synth.normal("modules.sim.v", (5, 512)).requires_grad_()
+    u = synth.normal("modules.sim.u", (5, 3, 512)).requires_grad_()
+    ws, wu = synth.normal("modules.sim.ws", (6, 5)), synth.normal("modules.sim.wu", (6, 5, 3))
+    s2, s3 = model.loose_similarity(q, v), model.loose_similarity(q, u)
+    ((s2 * ws).sum() + (s3 * wu).sum()).backward()
+    out.update(sim2=s2, sim3=s3, sim_dq=q.grad, sim_dv=v.grad, sim_du=u.grad)
+    save("modules_fp32", **out)
+
+
 def fx_manifest(mclip, mmodel, mopt, mmetrics):
     """state_dict layout (key -> shape, dtype) of the reference models as written (fp16 CLIP weights): what a
     pytorch_model.bin.N checkpoint of the reference holds (main_task_retrieval.py:215-222)."""
@@ -501,7 +553,7 @@ def fx_manifest(mclip, mmodel, mopt, mmetrics):
 
 FIXTURES = {"manifest": fx_manifest, "head": fx_head, "enc_tiny": fx_enc_tiny, "enc_rank": fx_enc_rank, "multisent": fx_multisent, "frame_sampling": fx_frame_sampling, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
             "enc_b16": fx_enc_b16, "enc_b32x8": fx_enc_b32x8,
-            "bertadam": fx_bertadam, "train_ft": fx_train_ft, "moco": fx_moco}
+            "bertadam": fx_bertadam, "train_ft": fx_train_ft, "moco": fx_moco, "modules": fx_modules}
 
 
 def main():

@@ -264,3 +264,65 @@ def test_resume_from_checkpoint_is_bit_identical(kind):
     steps(m2, opt2, batch2, 3, 6)
     bad = [k for k, v in m2.state_dict().items() if not torch.equal(v, ref[k])]
     assert not bad, f"{len(bad)} tensors differ after the resume: {bad[:8]}"
+
+
+def test_module_members_vs_reference_golden():
+    """MLP.forward (train mode twice, then eval mode), BertLMPredictionHead.forward and the differentiable loose_similarity of
+    the pre-training model as callables of their own (reference modules/modeling.py:788-807,207-229, modules/module_cross.py:
+    308-322) against what the reference's modules returned on the same seeded inputs (tests/golden/modules_fp32.npz)."""
+    from hmmc_amd.modeling import BirdPreTrainedModel
+    g = golden("modules_fp32")
+    cfg = task_config(contrast_num_negative=16, max_frames=4, dataset="chvtt")
+    sd = synth.pretrain_state(synth.TINY, 16, 4)
+    model = BirdPreTrainedModel.from_pretrained("cross-base", state_dict=sd, task_config=cfg).to(DEV).train()
+    mlp = model.v_projector
+    x = synth.normal("modules.mlp.x", (24, 512)).to(DEV).requires_grad_()
+    w = synth.normal("modules.mlp.w", (24, 512)).to(DEV)
+    y = mlp(x)
+    (y * w).sum().backward()
+    close(y, g["mlp_y"], 5e-5, 1e-4, "mlp y")
+    close(x.grad, g["mlp_dx"], 5e-6, 1e-3, "mlp dx")
+    close(mlp.linear_hidden[1].weight.grad[:8, :16], g["mlp_dw1"], 5e-5, 1e-3, "dw1")
+    close(mlp.linear_hidden[2].weight.grad[:64], g["mlp_dgamma"], 5e-5, 1e-3, "dgamma")
+    close(mlp.linear_hidden[2].bias.grad[:64], g["mlp_dbeta"], 5e-5, 1e-3, "dbeta")
+    close(mlp.linear_out.weight.grad[:8, :16], g["mlp_dw2"], 5e-5, 1e-3, "dw2")
+    close(mlp.linear_out.bias.grad[:64], g["mlp_db2"], 5e-5, 1e-3, "db2")
+    close(mlp.linear_hidden[2].running_mean[:64], g["mlp_running_mean1"], 1e-6, 1e-4, "running mean")
+    close(mlp.linear_hidden[2].running_var[:64], g["mlp_running_var1"], 1e-6, 1e-4, "running var")
+    with torch.no_grad():
+        y3 = mlp(synth.normal("modules.mlp.x3", (3, 8, 512)).to(DEV))            # leading dims are kept
+    close(y3, g["mlp_y3"], 5e-5, 1e-4, "mlp y3")
+    close(mlp.linear_hidden[2].running_var[:64], g["mlp_running_var2"], 1e-6, 1e-4, "running var 2")
+    assert int(mlp.linear_hidden[2].num_batches_tracked) == 2
+    mlp.eval()
+    with torch.no_grad():
+        ye = mlp(synth.normal("modules.mlp.xe", (10, 512)).to(DEV))
+    close(ye, g["mlp_y_eval"], 5e-5, 1e-4, "mlp eval")
+    with pytest.raises(RuntimeError):
+        mlp(x)                                                                   # eval mode is forward-only
+    mlp.train()
+    # MLM head
+    h = synth.normal("modules.lm.h", (3, 7, 512)).to(DEV).requires_grad_()
+    wl = synth.normal("modules.lm.w", (3, 7, 64)).to(DEV)
+    logits = model.cls(h)
+    assert logits.shape == (3, 7, 49408)
+    (logits[..., :64] * wl).sum().backward()
+    close(logits[..., :128], g["lm_logits_head"], 5e-5, 1e-4, "lm logits")
+    close(logits.sum(-1), g["lm_logits_rowsum"], 2e-2, 1e-4, "lm logits row sums")
+    close(h.grad, g["lm_dh"], 5e-6, 1e-3, "lm dh")
+    close(model.cls.transform.dense.weight.grad[:8, :16], g["lm_ddense"], 5e-6, 1e-3, "lm ddense")
+    close(model.cls.transform.LayerNorm.weight.grad[:64], g["lm_dln"], 5e-6, 1e-3, "lm dln")
+    close(model.cls.decoder.weight.grad[:8, :16], g["lm_ddec"], 5e-6, 1e-3, "lm ddec")
+    close(model.cls.bias.grad[:128], g["lm_dbias"], 5e-6, 1e-3, "lm dbias")
+    # loose_similarity: x100 logits within 1e-3 (north_star), gradients to both operands
+    q = synth.normal("modules.sim.q", (6, 512)).to(DEV).requires_grad_()
+    v = synth.normal("modules.sim.v", (5, 512)).to(DEV).requires_grad_()
+    u = synth.normal("modules.sim.u", (5, 3, 512)).to(DEV).requires_grad_()
+    ws, wu = synth.normal("modules.sim.ws", (6, 5)).to(DEV), synth.normal("modules.sim.wu", (6, 5, 3)).to(DEV)
+    s2, s3 = model.loose_similarity(q, v), model.loose_similarity(q, u)
+    ((s2 * ws).sum() + (s3 * wu).sum()).backward()
+    close(s2, g["sim2"], 1e-3, what="sim2")
+    close(s3, g["sim3"], 1e-3, what="sim3")
+    close(q.grad, g["sim_dq"], 5e-5, 1e-3, "sim dq")
+    close(v.grad, g["sim_dv"], 5e-5, 1e-3, "sim dv")
+    close(u.grad, g["sim_du"], 5e-5, 1e-3, "sim du")

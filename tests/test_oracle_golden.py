@@ -245,3 +245,56 @@ def test_pretrain_steps_fp32():
                     close(sd[key[3:]].detach().reshape(-1)[:16], g[key], 1e-5, 1e-4, key)
                 if key.startswith("q0:"):
                     close(queues[key[3:]][:32], g[key], 1e-5, what=key)
+
+
+def test_module_members_fp32():
+    """MLP.forward (train + eval), BertLMPredictionHead.forward and loose_similarity with gradients: the oracle's restatement
+    against what the reference's own modules returned (tests/golden/modules_fp32.npz, make_golden.py:fx_modules)."""
+    g = golden("modules_fp32")
+    sd = {k: v.clone() for k, v in synth.pretrain_state(synth.TINY, 16, 4).items()}
+    p = "v_projector."
+    x = synth.normal("modules.mlp.x", (24, 512)).requires_grad_()
+    w = synth.normal("modules.mlp.w", (24, 512))
+    for k in list(sd):
+        if k.startswith(p) and sd[k].is_floating_point() and "running" not in k:
+            sd[k] = sd[k].float().requires_grad_()
+    y, mean, var = O.mlp_forward(x, sd, p)
+    (y * w).sum().backward()
+    close(y.detach(), g["mlp_y"], 2e-5, 1e-5, "mlp y")
+    close(x.grad, g["mlp_dx"], 2e-6, 1e-4, "mlp dx")
+    close(sd[p + "linear_hidden.2.weight"].grad[:64], g["mlp_dgamma"], 2e-5, 1e-4, "dgamma")
+    close(sd[p + "linear_out.weight"].grad[:8, :16], g["mlp_dw2"], 2e-5, 1e-4, "dw2")
+    rm = 0.9 * sd[p + "linear_hidden.2.running_mean"] + 0.1 * mean.detach()
+    rv = 0.9 * sd[p + "linear_hidden.2.running_var"] + 0.1 * var.detach()
+    close(rm[:64], g["mlp_running_mean1"], 1e-6, 1e-5, "running mean")
+    close(rv[:64], g["mlp_running_var1"], 1e-6, 1e-5, "running var")
+    x3 = synth.normal("modules.mlp.x3", (3, 8, 512)).reshape(-1, 512)
+    with torch.no_grad():
+        y3, mean3, var3 = O.mlp_forward(x3, sd, p)
+        close(y3.view(3, 8, 512), g["mlp_y3"], 2e-5, 1e-5, "mlp y3")
+        sde = dict(sd)
+        sde[p + "linear_hidden.2.running_mean"] = 0.9 * rm + 0.1 * mean3
+        sde[p + "linear_hidden.2.running_var"] = 0.9 * rv + 0.1 * var3
+        close(sde[p + "linear_hidden.2.running_var"][:64], g["mlp_running_var2"], 1e-6, 1e-5, "running var 2")
+        ye, _, _ = O.mlp_forward(synth.normal("modules.mlp.xe", (10, 512)), sde, p, training=False)
+        close(ye, g["mlp_y_eval"], 2e-5, 1e-5, "mlp eval")
+    h = synth.normal("modules.lm.h", (3, 7, 512)).requires_grad_()
+    wl = synth.normal("modules.lm.w", (3, 7, 64))
+    sdl = {k: (v.float().requires_grad_() if k.startswith("cls.") else v) for k, v in sd.items()}
+    logits = O.mlm_head(h, sdl)
+    (logits[..., :64] * wl).sum().backward()
+    close(logits.detach()[..., :128], g["lm_logits_head"], 2e-5, 1e-5, "lm logits")
+    close(logits.detach().sum(-1), g["lm_logits_rowsum"], 5e-3, 1e-5, "lm logits row sums")
+    close(h.grad, g["lm_dh"], 2e-6, 1e-4, "lm dh")
+    close(sdl["cls.decoder.weight"].grad[:8, :16], g["lm_ddec"], 2e-6, 1e-4, "lm ddec")
+    close(sdl["cls.bias"].grad[:128], g["lm_dbias"], 2e-6, 1e-4, "lm dbias")
+    q = synth.normal("modules.sim.q", (6, 512)).requires_grad_()
+    v = synth.normal("modules.sim.v", (5, 512)).requires_grad_()
+    u = synth.normal("modules.sim.u", (5, 3, 512)).requires_grad_()
+    ws, wu = synth.normal("modules.sim.ws", (6, 5)), synth.normal("modules.sim.wu", (6, 5, 3))
+    s2, s3 = O.loose_similarity(q, v), O.loose_similarity(q, u)
+    ((s2 * ws).sum() + (s3 * wu).sum()).backward()
+    close(s2.detach(), g["sim2"], 1e-3, what="sim2")
+    close(s3.detach(), g["sim3"], 1e-3, what="sim3")
+    close(q.grad, g["sim_dq"], 2e-5, 1e-4, "sim dq")
+    close(u.grad, g["sim_du"], 2e-5, 1e-4, "sim du")
