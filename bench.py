@@ -285,6 +285,134 @@ def recorded_traffic(args, per_gpu_batch, launches_per_step):
     return round(rec["hbm_traffic_per_launch_bytes"]), f"{rel} (rocprofv3 --pmc, separate passes)"
 
 
+HBM_PEAK_TBS = 8.0                  # HBM3E, MI355X_MICROARCH.md (6.3 TB/s measured on a float4 copy)
+
+
+def _time_us(fn, reps=10):
+    """average microseconds of fn() over `reps` launches, HIP events on the current stream (after one untimed call)"""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def hbm_rooflines(dev, b, frames, dims, params, optimizer, model, pretrain):
+    """north_star: "rocprof HBM GB/s ... reported against peak" for the HBM-bound kernels of the step.  Each kernel alone, on
+    this rank's shapes (one ViT layer's LayerNorm / attention; the whole model's optimizer), timed with events on the current
+    stream; bytes = algorithmic (every operand once).  The clip + BertAdam figures include their small helper launches."""
+    from hmmc_amd import ops
+    from hmmc_amd.optimization import clip_grad_norm_
+    g = dims.image_res // dims.patch
+    L, D, H = g * g + 1, dims.vision_width, dims.vision_width // 64
+    nseq = b * frames
+    T = nseq * L
+    gen = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn((T, D), generator=gen, device=dev).half()
+    dy = torch.randn((T, D), generator=gen, device=dev).half()
+    dres = torch.randn((T, D), generator=gen, device=dev).half()
+    gm, bt = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    y, mean, rstd = ops.layernorm_fwd(x, gm, bt, 1e-5)
+    qkv = torch.randn((T, 3 * D), generator=gen, device=dev).half()
+    att, lse = ops.attention_f16_fwd(qkv, nseq, L, H, False)
+    rows = []
+
+    def add(kernel, nbytes, us):
+        rows.append({"kernel": kernel, "bytes": int(nbytes), "us": round(us, 1), "tb_per_s": round(nbytes / us / 1e6, 2),
+                     "frac_of_hbm_peak": round(nbytes / us / 1e6 / HBM_PEAK_TBS, 3)})
+    add(f"ln_fwd [{T}, {D}] fp16", 2 * T * D * 2, _time_us(lambda: ops.layernorm_fwd(x, gm, bt, 1e-5)))
+    add(f"ln_bwd [{T}, {D}] fp16 (+ residual gradient, dx column sums)", 4 * T * D * 2,
+        _time_us(lambda: ops.layernorm_bwd(dy, x, gm, mean, rstd, dres=dres, want_colsum=True)))
+    add(f"attn_fwd {nseq} x {L} tokens x {H} heads", 4 * T * D * 2, _time_us(lambda: ops.attention_f16_fwd(qkv, nseq, L, H, False)))
+    add(f"attn_bwd {nseq} x {L} tokens x {H} heads (+ in_proj bias partials)", 7 * T * D * 2,
+        _time_us(lambda: ops.attention_f16_bwd(qkv, att, lse, dy, nseq, L, H, False, want_dbias=True)))
+    del x, dy, dres, y, qkv, att, lse
+    pbytes = sum(p.numel() * p.element_size() for p in params)
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    lr_state = [(grp, grp["lr"]) for grp in optimizer.param_groups]
+    for grp, _ in lr_state:
+        grp["lr"] = 0.0                                      # same kernels and traffic, the weights stay as they are
+    add(f"clip_grad_norm_ ({len(params)} tensors, {pbytes / 1e6:.0f} MB: read twice, scaled in place)", 3 * pbytes,
+        _time_us(lambda: clip_grad_norm_(params, 1.0), reps=5))
+    add(f"BertAdam.step ({len(params)} tensors: p, g, m, v in; p, m, v out)", 7 * pbytes, _time_us(optimizer.step, reps=5))
+    for grp, lr in lr_state:
+        grp["lr"] = lr
+    if pretrain:
+        nb = sum(p.numel() * p.element_size() for pair in model.model_pairs for p in pair[0].parameters())
+        m0 = model.contrast_momentum
+        model.contrast_momentum = 1.0                        # p_k = p_k * 1 + p * 0: same launch, the keys stay as they are
+        add("momentum update (mt_ema: p_k, p in; p_k out)", 3 * nb, _time_us(model._momentum_update, reps=5))
+        model.contrast_momentum = m0
+    return rows
+
+
+def comm_leg(args, dev, model, net, params, step, b, frames, repeats=5):
+    """world > 1: what the first scaling curve needs beside it - the gradient all-reduce in DDP's bucket sizes
+    (main_task_retrieval.py:207-208), the packed feature all-gather and the reduce-scatter of its gradient (one collective
+    each for the reference's three all_gathers, modules/modeling.py:698-700), each alone on an idle GPU, and a step without
+    gradient synchronisation (DDP.no_sync)."""
+    world = dist.get_world_size()
+    flat = dist.get_backend() == "nccl"
+    sizes = [p.numel() * p.element_size() for p in params]
+    limits = [1024 * 1024, int(getattr(net, "bucket_bytes_cap", 25 * 1024 * 1024))]
+    try:
+        buckets, _ = dist._compute_bucket_assignment_by_size(list(reversed(params)), limits)
+        bucket_bytes = [sum(sizes[len(params) - 1 - i] for i in idx) for idx in buckets]
+    except Exception:                                                        # private helper: fall back to the cap alone
+        total, bucket_bytes = sum(sizes), []
+        while total > 0:
+            bucket_bytes.append(min(total, limits[1]))
+            total -= bucket_bytes[-1]
+    bufs = [torch.zeros(max(nb // 2, 1), dtype=torch.float16, device=dev) for nb in bucket_bytes]
+
+    def allreduce_all():
+        works = [dist.all_reduce(t, async_op=True) for t in bufs]
+        for w in works:
+            w.wait()
+    E = 512
+    packed = torch.zeros((b, (frames + 2) * E), dtype=torch.float32, device=dev)
+    gathered = torch.zeros((b * world, (frames + 2) * E), dtype=torch.float32, device=dev)
+
+    def gather():
+        if flat:
+            dist.all_gather_into_tensor(gathered, packed)
+        else:
+            dist.all_gather(list(gathered.chunk(world, dim=0)), packed)
+
+    def scatter():
+        if flat:
+            dist.reduce_scatter_tensor(packed, gathered, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(gathered, op=dist.ReduceOp.SUM)                  # the gloo form of _AllGatherCat.backward
+    out = {"backend": dist.get_backend(), "grad_bytes": int(sum(sizes)), "buckets": len(bucket_bytes),
+           "bucket_bytes_max": int(max(bucket_bytes)), "allreduce_ms": round(_time_us(allreduce_all, repeats) / 1e3, 3),
+           "feature_bytes_per_rank": int(packed.numel() * 4), "allgather_ms": round(_time_us(gather, repeats) / 1e3, 3),
+           "reduce_scatter_ms": round(_time_us(scatter, repeats) / 1e3, 3)}
+    out["allreduce_bus_gb_per_s"] = round(2 * (world - 1) / world * out["grad_bytes"] / (out["allreduce_ms"] * 1e-3) / 1e9, 1)
+    if hasattr(net, "no_sync"):
+        with net.no_sync():
+            step(10 ** 6)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(3):
+                step(10 ** 6 + 1 + i)
+            torch.cuda.synchronize()
+            out["step_ms_no_sync"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+    t = torch.tensor([out["allreduce_ms"], out["allgather_ms"], out["reduce_scatter_ms"], out.get("step_ms_no_sync", 0.0)],
+                     dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                                 # slowest rank, like the timed region
+    out["allreduce_ms"], out["allgather_ms"], out["reduce_scatter_ms"] = [round(float(v), 3) for v in t[:3]]
+    if "step_ms_no_sync" in out:
+        out["step_ms_no_sync"] = round(float(t[3]), 2)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,7 +422,11 @@ def main():
     ap.add_argument("--eval-videos", type=int, default=1500, help="--mode eval: candidate videos")
     ap.add_argument("--mode", choices=("finetune", "pretrain", "eval"), default="finetune",
                     help="finetune: BirdModel (configs 2/3/5); pretrain: BirdPreTrainedModel, FAM+VTM+FTM+MLM, MoCo queues (config 4)")
-    ap.add_argument("--batch", type=int, default=None, help="global batch (reference --batch_size); default 256 / 128 (pretrain)")
+    ap.add_argument("--batch", type=int, default=None, help="global batch (reference --batch_size); default 256 / 128 (pretrain); "
+                                                            "with --scaling weak: the batch PER GPU")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong (default): --batch is the global batch, split over ranks (the reference's --batch_size semantics, "
+                         "dataloaders/dataloader.py:84); weak: --batch per GPU, global batch = batch x gpus (SURVEY 8d)")
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--length", type=int, default=32, help="caption length (fine-tune)")
     ap.add_argument("--title-length", type=int, default=45)
@@ -358,8 +490,11 @@ def main():
         import hmmc_amd.functional as _fn0
         import hmmc_amd.modeling as _md0
         _md0._OVERLAP_TOWERS, _fn0._WGRAD_STREAM = False, False
-    assert args.batch % world == 0
-    b = args.batch // world
+    if args.scaling == "weak":
+        b, args.batch = args.batch, args.batch * world              # --batch was per GPU; from here on args.batch is global
+    else:
+        assert args.batch % world == 0
+        b = args.batch // world
     dims = synth.NAMED[args.clip]
     pretrain = args.mode == "pretrain"
     extra = dict(dataset="chvtt", contrast_momentum=0.99, contrast_temperature=0.07, contrast_num_negative=args.negatives,
@@ -442,25 +577,33 @@ def main():
     if args.vit_forward_iters > 0:
         frames_flat = video.view(b * args.frames, 3, res, res)
         enc = model.visual_encoder
-        with torch.no_grad():
-            enc.encode_image(frames_flat)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.vit_forward_iters):
-                enc.encode_image(frames_flat)
-            e1.record()
-            torch.cuda.synchronize()
-        vms = e0.elapsed_time(e1) / args.vit_forward_iters
+
+        def vit_ms():
+            with torch.no_grad():
+                return _time_us(lambda: enc.encode_image(frames_flat), args.vit_forward_iters) / 1e3
+        policy = _fn._FOLD_LN
+        vms = vit_ms()
+        _fn._FOLD_LN = "0"                                  # the same pass on the unfolded kernels (HMMC_FOLD_LN=0), for the record
+        vms_unfolded = vit_ms()
+        _fn._FOLD_LN = policy
         vtf = b * args.frames * fm["frame_fwd"] / (vms * 1e-3) / 1e12
         vte = b * args.frames * fm["frame_fwd_executed"] / (vms * 1e-3) / 1e12
         vit_forward = {"ms": round(vms, 3), "frames": b * args.frames, "tflops_executed": round(vte, 1),
                        "frac_of_mfma_peak": round(vte / MFMA_PEAK_TFLOPS, 4),
                        "tflops_reference_formulation": round(vtf, 1),
                        "frac_of_mfma_peak_reference_formulation": round(vtf / MFMA_PEAK_TFLOPS, 4),
-                       "note": "frame encoder forward (patch embed + blocks + ln_post/proj) of one rank's frames, no_grad; "
-                               "frac_of_mfma_peak counts the FLOPs this path executes (last block's per-token half and the "
-                               "projection on the class token only), the reference-formulation figure counts the reference's"}
+                       "ln_fold_policy": policy,
+                       "ms_unfolded_kernels": round(vms_unfolded, 3),
+                       "frac_of_mfma_peak_unfolded_kernels": round(vte * vms / vms_unfolded / MFMA_PEAK_TFLOPS, 4),
+                       "note": "frame encoder forward (patch embed + blocks + ln_post/proj) of one rank's frames, no_grad, as the "
+                               "product runs it by default: ln_1 / ln_2 folded into in_proj / c_fc (hmmc_tower_fwd_fused; same "
+                               "FLOPs, no LayerNorm pass; as close to the reference's fp32 regime as the reference's own fp16 "
+                               "regime, tests/test_gpu_fold.py); *_unfolded_kernels: HMMC_FOLD_LN=0, the kernels whose rounding "
+                               "points follow the reference's. frac_of_mfma_peak counts the FLOPs this path executes (last block's "
+                               "per-token half and the projection on the class token only), the reference-formulation figure "
+                               "counts the reference's"}
+    hbm = hbm_rooflines(dev, b, args.frames, dims, params, optimizer, model, pretrain) if world == 1 else None
+    comm = comm_leg(args, dev, model, net, params, step, b, args.frames) if world > 1 else None
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -496,7 +639,7 @@ def main():
                   f"video-text pairs/sec (whole node), {args.mode} {args.clip} B={args.batch} F={args.frames} {res}^2")
         out = {"metric": metric, "value": round(value, 2),
                "unit": "video-text pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                "dtype": "f16", "data": "synthetic",
                "config": {"workload": workload, "mode": args.mode, "global_batch": args.batch, "per_gpu_batch": b, "frames": args.frames,
                           "parallelism": f"dp{world}", "streams": "single" if args.single_stream else "overlapped",
@@ -505,7 +648,7 @@ def main():
                "step_tflops": round(value * per_pair_exec / 1e12, 1) if per_pair_exec else None,
                "step_tflops_reference_formulation": round(value * per_pair / 1e12, 1) if per_pair else None,
                "mfma_frac_whole_step": round(value * (per_pair_exec or per_pair) / 1e12 / (world * MFMA_PEAK_TFLOPS), 4) if per_pair else None,
-               "final_loss": round(final_loss, 4), "roofline": roof, "vit_forward": vit_forward,
+               "final_loss": round(final_loss, 4), "roofline": roof, "roofline_hbm": hbm, "comm": comm, "vit_forward": vit_forward,
                "peak_device_memory_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(12, 32)

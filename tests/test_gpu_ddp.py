@@ -358,3 +358,15 @@ def test_bench_self_launches_two_ranks():
     assert out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["final_loss"] == out["final_loss"] and abs(out["final_loss"]) < 50       # finite
     assert out["config"]["gemm_reserved_cus"] == 16 and out["roofline"]["launches_per_step"] > 0
+    # the communication record a first scaling curve is read against (bench.py:comm_leg)
+    comm = out["comm"]
+    for key in ("allreduce_ms", "allgather_ms", "reduce_scatter_ms", "step_ms_no_sync", "grad_bytes", "buckets", "allreduce_bus_gb_per_s"):
+        assert comm[key] > 0, (key, comm)
+    assert comm["backend"] == "gloo" and comm["feature_bytes_per_rank"] == 4 * (4 + 2) * 512 * 4
+    # weak scaling: --batch is per GPU, the line says so
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scaling", "weak", "--batch", "4", "--frames", "4",
+                        "--steps", "1", "--warmup", "1", "--roofline-steps", "1", "--vit-forward-iters", "0", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "weak" and out["config"]["per_gpu_batch"] == 4 and out["config"]["global_batch"] == 8
