@@ -244,6 +244,10 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
     // a query tile's Q / dO / O rows, lane-ordered (row (lane >> 3) + 8 t, bytes 16 (lane & 7) .. +15), and its log-sum-exp
     u4v rq[2], rd[2], ro[2];
     float rl;
+    // INVARIANT (the s_waitcnt vmcnt(6) below counts on it): load_tile is exactly TILE_LOADS = 7 vector-memory loads - six 16-byte
+    // loads (16-byte aligned: one instruction each, nothing to merge or split) and one dword - every result is consumed, and the
+    // "memory" clobber of the wait keeps all seven in front of it.  Changing the number of loads here means changing that count.
+    constexpr int TILE_LOADS = 7;
     auto load_tile = [&](int qt) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
     };
     load_tile(min(wid, nt - 1));                 // requested BEFORE the DMAs below: the in-order vmcnt then does not make the
                                                  // first tile wait for 56 KiB of images
+    static_assert(TILE_LOADS == 7, "the wait below leaves TILE_LOADS - 1 loads in flight");
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but 6 of those 7 loads: the K / V images of this head (older) have landed
     __syncthreads();
     {                                            // this head's Q and dO images: needed in phase 2, in flight under phase 1
@@ -271,6 +276,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
 #endif
 #ifndef HMMC_ATTN_SKIP
 #define HMMC_ATTN_SKIP 0          // timing / register experiments (scratch/): 1 skips phase 1, 2 skips phase 2 (wrong results)
+#endif
+#if HMMC_ATTN_SKIP != 0 && !defined(HMMC_SCRATCH)
+#error "HMMC_ATTN_SKIP builds compute wrong results: scratch experiments only (-DHMMC_SCRATCH)"
 #endif
     for (int qt = wid; qt < nt && HMMC_ATTN_SKIP != 1; qt += NW) {
       const int q0 = qt * 16, qi = q0 + c;

@@ -516,8 +516,12 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
   // query gradient, the MLM data gradient), behind for K = 512, where the fixed ~6 us of fill and reduction decide.
   {
     static const bool off = std::getenv("HMMC_NO_F32_WAVEK") != nullptr;          // A/B runs
-    static const char* force_s = std::getenv("HMMC_F32_PICK");                    // scratch: 1 small, 2 tiled, 3.. wave-split-K RM = 2, 3, 4, 6
+#ifdef HMMC_SCRATCH      // scratch/gemm32_pick.py builds: HMMC_F32_PICK = 1 small, 2 tiled, 3.. wave-split-K RM = 2, 3, 4, 6
+    static const char* force_s = std::getenv("HMMC_F32_PICK");
     const int force = force_s ? atoi(force_s) : 0;
+#else
+    const int force = 0;
+#endif
     const bool av = sak == 1 && p.avec && !(K & 3), bv = sbk == 1 && p.bvec && !(K & 3);
     static const int rms[4] = {2, 3, 4, 6};
     double best = t_small < t_tiled ? t_small : t_tiled;
@@ -544,8 +548,12 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
       return hmmc_launch_status();
     }
   }
+#ifdef HMMC_SCRATCH
   static const char* force2_s = std::getenv("HMMC_F32_PICK");
   const int force2 = force2_s ? atoi(force2_s) : 0;
+#else
+  const int force2 = 0;
+#endif
   if (force2 == 1 || (force2 != 2 && t_small < t_tiled)) {
     long small = (long)((M + 15) / 16) * ((N + 31) / 32);
     const bool av = sak == 1 && p.avec && !(K & 3), bv = sbk == 1 && p.bvec && !(K & 3);

@@ -122,10 +122,13 @@ extern "C" size_t hmmc_tower_act_bytes(long tokens, int D, int nseq, int L, int 
 // transient gradients of the backward: dh [T,4D], dqkv [T,3D], dln [T,D], dx1 [T,D], ping/pong dx [T,D] x2; the fp16 tower holds
 // dh / dqkv / dx1 twice (layers alternate): a layer's grouped weight-gradient launch reads them while the next layer's chain
 // already writes its own
+static size_t group_ws_bytes(long tokens, int D);
+// the second set exists only where a grouped launch can read one set while the next layer's chain writes the other
+static bool two_sets(long tokens, int D, int fp32) { return !fp32 && group_ws_bytes(tokens, D) > 0; }
 extern "C" size_t hmmc_tower_bwd_scratch_bytes(long tokens, int D, int fp32) {
   size_t es = fp32 ? 4 : 2;
   const size_t set = al((size_t)tokens * 4 * D * es) + al((size_t)tokens * 3 * D * es) + al((size_t)tokens * D * es);
-  return (fp32 ? 1 : 2) * set + 3 * al((size_t)tokens * D * es);
+  return (two_sets(tokens, D, fp32) ? 2 : 1) * set + 3 * al((size_t)tokens * D * es);
 }
 
 // fp32 partial sums of the fp16 tower's deferred reductions, one slot per layer (hmmc_tower_bwd reduces all of them in one
@@ -373,12 +376,13 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
   const size_t slab = hmmc_tower_act_bytes(T, D, nseq, L, heads, fp32);
   char* sp = (char*)scratch;
   void* dh_set[2]; void* dqkv_set[2]; void* dx1_set[2];
-  for (int k = 0; k < (f32 ? 1 : 2); ++k) {
+  const bool sets2 = two_sets(T, D, fp32);
+  for (int k = 0; k < (sets2 ? 2 : 1); ++k) {
     dh_set[k] = sp; sp += al((size_t)T * 4 * D * es);
     dqkv_set[k] = sp; sp += al((size_t)T * 3 * D * es);
     dx1_set[k] = sp; sp += al((size_t)T * D * es);
   }
-  if (f32) { dh_set[1] = dh_set[0]; dqkv_set[1] = dqkv_set[0]; dx1_set[1] = dx1_set[0]; }
+  if (!sets2) { dh_set[1] = dh_set[0]; dqkv_set[1] = dqkv_set[0]; dx1_set[1] = dx1_set[0]; }
   void* dln = sp; sp += al((size_t)T * D * es);
   void* ping[2];
   ping[0] = sp; sp += al((size_t)T * D * es);

@@ -432,8 +432,16 @@ class _Recorder:
 
 
 def fx_moco(mclip, mmodel, mopt, mmetrics):
-    dims = synth.TINY
-    K, B, Fr = 16, 4, 4
+    _moco_fixture(mclip, mmodel, mopt, "moco", synth.TINY, K=16, B=4, Fr=4, steps=5)
+
+
+def fx_moco_b32(mclip, mmodel, mopt, mmetrics):
+    """BASELINE config 4's model at TRUE ViT-B/32 dimensions (four CLIP towers, K = 1 024 negatives, title 45 / tag 25), B = 4,
+    F = 2, two optimizer steps, both regimes (round 4: the pre-training step had only been pinned at width 128)."""
+    _moco_fixture(mclip, mmodel, mopt, "moco_b32", synth.VIT_B32, K=1024, B=4, Fr=2, steps=2, queue_steps=(0, 1))
+
+
+def _moco_fixture(mclip, mmodel, mopt, name, dims, K, B, Fr, steps, queue_steps=(0, 3, 4)):
     sd = synth.pretrain_state(dims, K, Fr)
     for mode in ("fp32", "aswritten"):
         model, cfg = build_reference_model(mclip, mmodel.BirdPreTrainedModel, dims, sd, mode, contrast_num_negative=K,
@@ -451,8 +459,8 @@ def fx_moco(mclip, mmodel, mopt, mmetrics):
             setattr(model, nm, wrap)
         out = {"K": K, "B": B, "F": Fr}
         torch.manual_seed(1234)
-        for step in range(5):
-            batch = synth.pretrain_batch(B, Fr, tag=f"moco.s{step}")
+        for step in range(steps):
+            batch = synth.pretrain_batch(B, Fr, res=dims.image_res, tag=f"{name}.s{step}")
             vid, vf, tg, gm, ti, tm = batch
             with _Recorder() as rec:
                 loss = model(vid, vf, tg, gm, ti, tm, step + 1)
@@ -474,11 +482,11 @@ def fx_moco(mclip, mmodel, mopt, mmetrics):
                       "v_projector.linear_hidden.2.running_mean", "v_projector.linear_hidden.2.running_var",
                       "v_projector_k.linear_hidden.2.running_mean", "v_predictor.linear_hidden.2.running_var"):
                 out[f"s{step}:{k}"] = S[k].reshape(-1)[:16].clone()
-            if step in (0, 3, 4):
+            if step in queue_steps:
                 for qn in ("queue_v_cross_ng", "queue_title_cross_ng", "queue_tag_cross_ng", "queue_frame_proj_ng",
                            "queue_frame_cross_ng"):
-                    out[f"q{step}:{qn}"] = S[qn][:32].clone()   # first 32 of 512 feature rows, all columns
-        save(f"moco_{mode}", **out)
+                    out[f"q{step}:{qn}"] = S[qn][:32, :64].clone()   # first 32 of 512 feature rows, the columns written so far
+        save(f"{name}_{mode}", **out)
 
 
 def fx_modules(mclip, mmodel, mopt, mmetrics):
@@ -553,7 +561,7 @@ def fx_manifest(mclip, mmodel, mopt, mmetrics):
 
 FIXTURES = {"manifest": fx_manifest, "head": fx_head, "enc_tiny": fx_enc_tiny, "enc_rank": fx_enc_rank, "multisent": fx_multisent, "frame_sampling": fx_frame_sampling, "enc_tiny16": fx_enc_tiny16, "enc_b32": fx_enc_b32,
             "enc_b16": fx_enc_b16, "enc_b32x8": fx_enc_b32x8,
-            "bertadam": fx_bertadam, "train_ft": fx_train_ft, "moco": fx_moco, "modules": fx_modules}
+            "bertadam": fx_bertadam, "train_ft": fx_train_ft, "moco": fx_moco, "moco_b32": fx_moco_b32, "modules": fx_modules}
 
 
 def main():

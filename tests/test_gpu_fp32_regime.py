@@ -167,3 +167,37 @@ def test_fp32_pretrain_steps_vs_reference_golden():
                     close(S[key[3:]].reshape(-1)[:16], g[key], 1e-5, 1e-4, key)
                 if key.startswith("q0:"):
                     close(S[key[3:]][:32], g[key], 1e-5, what=key)
+
+
+def test_fp32_pretrain_at_true_vit_b32_dims_vs_reference_golden():
+    """BASELINE config 4's model at TRUE ViT-B/32 dimensions - four CLIP towers of width 768 / 512, K = 1 024 negatives, title
+    45 / tag 25 tokens - B = 4, F = 2, two optimizer steps in fp32 against the reference (tests/golden/moco_b32_fp32.npz): every
+    loss part 2e-3, the global gradient norm, EMA'd key weights, BN running statistics, and the queue columns written 1e-5."""
+    from hmmc_amd.modeling import BirdPreTrainedModel
+    from hmmc_amd.optimization import clip_grad_norm_
+    g = golden("moco_b32_fp32")
+    K, B, Fr = int(g["K"]), int(g["B"]), int(g["F"])
+    model = build(synth.VIT_B32, cls=BirdPreTrainedModel, sd=synth.pretrain_state(synth.VIT_B32, K, Fr), contrast_num_negative=K,
+                  max_frames=Fr, dataset="chvtt", lr=2e-3, text_lr=1e-3, coef_lr=0.5, weight_decay=0.05)
+    opt = prep_optimizer(model, model.task_config, 10)
+    for step in range(2):
+        vid, vf, tg, gm, ti, tm = [t.to(DEV) for t in synth.pretrain_batch(B, Fr, tag=f"moco_b32.s{step}")]
+        model._mlm_draws = [torch.from_numpy(g[f"mlm_{n}{step}"]) for n in ("masked", "replaced", "randsel", "words")]
+        loss = model(vid, vf, tg, gm, ti, tm, step + 1)
+        loss.backward()
+        tn = clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        fam, vtm, ftm, mlm = [float(x.detach()) for x in model.last_losses]
+        close(fam, g[f"fam{step}"], 2e-3, what=f"fam{step}")
+        close(ftm, g[f"ftm{step}"], 2e-3, what=f"ftm{step}")
+        close(mlm, g[f"mlm{step}"], 2e-3, what=f"mlm{step}")
+        close(loss, g[f"loss{step}"], 2e-3, what=f"loss{step}")
+        close(tn, g[f"gnorm{step}"], 0, 5e-3, f"gnorm{step}")
+        assert int(model.queue_ptr) == int(g[f"ptr{step}"][0]) == B * (step + 1), "queue pointer"
+        S = model.state_dict()
+        for key in g.files:
+            if key.startswith(f"s{step}:"):
+                close(S[key.split(":", 1)[1]].reshape(-1)[:16], g[key], 2e-5 if step == 0 else 2e-4, 1e-3, key)
+            if key.startswith(f"q{step}:"):
+                close(S[key.split(":", 1)[1]][:32, :64], g[key], 1e-5 if step == 0 else 2e-4, what=key)

@@ -79,11 +79,12 @@ def test_gemm_big_tile_exact_integers(layout, M, N, K):
     assert torch.equal(c.float(), ref), f"max diff {(c.float()-ref).abs().max()}"
 
 
-@pytest.mark.parametrize("T,D", [(2048, 256), (4480, 512), (19200, 768), (40000, 768)])
+@pytest.mark.parametrize("T,D", [(2048, 256), (4480, 512), (19200, 768), (40000, 768), (2056, 256), (5000, 512), (12344, 768), (2120, 768)])
 def test_gemm_grouped_weight_gradients_exact_integers(T, D):
     """The four weight gradients of a layer in one grouped launch (hmmc_gemm_f16_wgrad_group): bit-exact on integer data
-    against fp32 torch for every problem, with token counts that are not multiples of the K tile or of the split, and the
-    same results as one hmmc_gemm_f16 call per gradient."""
+    against fp32 torch for every problem, and the same results as one hmmc_gemm_f16 call per gradient.  Token counts: multiples
+    of the 64-token K tile (2048 ... 40000), counts that are not (2056, 5000, 12344: the K tail of the grouped kernel; T % 8 == 0
+    is the operand alignment), and 2120 tokens = 34 K-tiles, whose last split holds fewer K-tiles than the others."""
     g = torch.Generator().manual_seed(T + D)
     dims = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)]                      # c_proj, c_fc, out_proj, in_proj
     dys = [torch.randint(-2, 3, (T, n), generator=g).half().to(DEV) for n, _ in dims]

@@ -326,3 +326,37 @@ def test_module_members_vs_reference_golden():
     close(q.grad, g["sim_dq"], 5e-5, 1e-3, "sim dq")
     close(v.grad, g["sim_dv"], 5e-5, 1e-3, "sim dv")
     close(u.grad, g["sim_du"], 5e-5, 1e-3, "sim du")
+
+
+def test_pretrain_as_written_at_true_vit_b32_dims_vs_reference_golden():
+    """The same two steps at true ViT-B/32 dimensions in the as-written (fp16 tower) regime, against the reference's as-written
+    run inside the reference's own envelope: every loss part of step 0 within 1.5 x |as-written - fp32| (or 2e-2), the queue
+    columns the first enqueue wrote within 2e-3, step 1 finite and within 0.25 of the reference's."""
+    from hmmc_amd.modeling import BirdPreTrainedModel
+    from hmmc_amd.optimization import clip_grad_norm_
+    ga, gf = golden("moco_b32_aswritten"), golden("moco_b32_fp32")
+    K, B, Fr = int(ga["K"]), int(ga["B"]), int(ga["F"])
+    cfg = task_config(contrast_num_negative=K, max_frames=Fr, dataset="chvtt", lr=2e-3, text_lr=1e-3, coef_lr=0.5, weight_decay=0.05)
+    model = BirdPreTrainedModel.from_pretrained("cross-base", state_dict=synth.pretrain_state(synth.VIT_B32, K, Fr), task_config=cfg)
+    model = model.to(DEV).train()
+    opt = prep_optimizer(model, cfg, 10)
+    for step in range(2):
+        vid, vf, tg, gm, ti, tm = [t.to(DEV) for t in synth.pretrain_batch(B, Fr, tag=f"moco_b32.s{step}")]
+        model._mlm_draws = [torch.from_numpy(ga[f"mlm_{n}{step}"]) for n in ("masked", "replaced", "randsel", "words")]
+        loss = model(vid, vf, tg, gm, ti, tm, step + 1)
+        loss.backward()
+        clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        parts = dict(zip(("fam", "vtm", "ftm", "mlm"), [float(x.detach()) for x in model.last_losses]))
+        for nm in ("fam", "ftm", "mlm"):
+            ref, env = float(ga[f"{nm}{step}"]), 1.5 * abs(float(ga[f"{nm}{step}"]) - float(gf[f"{nm}{step}"]))
+            print(f"step {step} {nm}: {parts[nm]:.5f} (as-written reference {ref:.5f}, its fp32 regime {float(gf[f'{nm}{step}']):.5f})")
+            assert abs(parts[nm] - ref) <= (max(env, 2e-2) if step == 0 else 0.25), (step, nm, parts[nm], ref)
+        assert int(model.queue_ptr) == int(ga[f"ptr{step}"][0])
+        if step == 0:
+            S = model.state_dict()
+            for key in ga.files:
+                if key.startswith("q0:"):
+                    close(S[key[3:]][:32, :64], ga[key], 2e-3, what=key)
+    ops.raise_on_device_errors()

@@ -298,3 +298,27 @@ def test_module_members_fp32():
     close(s3.detach(), g["sim3"], 1e-3, what="sim3")
     close(q.grad, g["sim_dq"], 2e-5, 1e-4, "sim dq")
     close(u.grad, g["sim_du"], 2e-5, 1e-4, "sim du")
+
+
+def test_pretrain_forward_at_true_vit_b32_dims_fp32():
+    """BASELINE config 4's model at true ViT-B/32 dimensions (K = 1 024, title 45 / tag 25, B = 4, F = 2): every loss part of the
+    first step and the enqueued keys against the reference (tests/golden/moco_b32_fp32.npz; forward only - the CPU suite's time)."""
+    g = golden("moco_b32_fp32")
+    K, B, Fr = int(g["K"]), int(g["B"]), int(g["F"])
+    sd = {k: v.clone() for k, v in synth.pretrain_state(synth.VIT_B32, K, Fr).items()}
+    sd["cls.decoder.bias"] = sd["cls.bias"]
+    queues = {k: sd[k] for k in sd if k.startswith("queue_") and k != "queue_ptr"}
+    batch = synth.pretrain_batch(B, Fr, tag="moco_b32.s0")
+    draws = [t(g[f"mlm_{n}0"]) for n in ("masked", "replaced", "randsel", "words")]
+    draws = [d.bool() if i < 3 else d for i, d in enumerate(draws)]
+    with torch.no_grad():
+        loss, parts, ptr = O.pretrain_loss(batch, sd, queues, 0, K, mode="fp32", mlm_draws=draws)
+    fam, vtm, ftm, mlm = [float(x) for x in parts]
+    close(fam, g["fam0"], 2e-3, what="fam0")
+    close(ftm, g["ftm0"], 2e-3, what="ftm0")
+    close(mlm, g["mlm0"], 2e-3, what="mlm0")
+    close(loss, g["loss0"], 2e-3, what="loss0")
+    assert ptr == int(g["ptr0"][0]) == B
+    for key in g.files:
+        if key.startswith("q0:"):
+            close(queues[key[3:]][:32, :64], g[key], 1e-5, what=key)
