@@ -20,15 +20,20 @@ SIGNATURES = {
     "hmmc_gemm_f16_workspace": ("iii", "z"),
     "hmmc_gemm_f16_colsum_rows": ("iii", "z"),
     "hmmc_gemm_f16": ("pppiiiiiiiippppipzp", "i"),
-    "hmmc_gemm_f16_fold": ("pppiiiiiippipppp", "i"),
+    "hmmc_gemm_f16_fold": ("pppiiiiiiippppippppzp", "i"),
+    "hmmc_layernorm_bwd_fold_rows": ("i", "i"),
+    "hmmc_layernorm_bwd_fold": ("ppppppiiilp", "i"),
+    "hmmc_fold_grad_finish": ("ppppppppppiip", "i"),
+    "hmmc_attention_f16_bwd_scaled": ("pppppppiiiip", "i"),
+    "hmmc_tower_bwd_fold": ("pppppppzpiiiiiiiipzpp", "i"),
     "hmmc_ln_fold_prep": ("pppppppiip", "i"),
     "hmmc_rowstat": ("ppiilfp", "i"),
     "hmmc_rowstat_finalize": ("ppiiifp", "i"),
-    "hmmc_tower_fold_bytes": ("lii", "z"),
-    "hmmc_tower_fwd_fused": ("pppppiiiiiifipzp", "i"),
+    "hmmc_tower_fold_bytes": ("liii", "z"),
+    "hmmc_tower_fwd_fused": ("pppppiiiiiiifiipzp", "i"),
     "hmmc_vit_embed_ln": ("pppppppppiiifip", "i"),
     "hmmc_gemm_f16_wgrad_group_workspace": ("ppii", "z"),
-    "hmmc_gemm_f16_wgrad_group": ("pppppiipzp", "i"),
+    "hmmc_gemm_f16_wgrad_group": ("ppppppiipzp", "i"),
     "hmmc_gemm_reserve_cus": ("i", "i"),
     "hmmc_gemm_profile_start": ("", "i"),
     "hmmc_gemm_profile_stop": ("pppp", "i"),

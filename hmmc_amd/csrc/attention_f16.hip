@@ -209,6 +209,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   }
 
   float* dbias = p.dbias ? p.dbias + (long)n * 3 * D + h * DH : nullptr;   // + type * D
+  float rs[KT];                                  // row factor of token t*16 + c (1 without p.rowstat)
+#pragma unroll
+  for (int t = 0; t < KT; ++t) rs[t] = p.rowstat ? p.rowstat[2 * ((long)n * L + min(t * 16 + c, L - 1))] : 1.0f;
   f4 csum[4];
   // ---- phase 1: keys on the lane's rows -> delta and dQ (the tile holds K)
 #pragma unroll
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane),
                                                          cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[dt], 0, 0, 0);
     }
-    store_rows(dq, ld, acc, qt * 16, L, scr, lane);
+    store_rows(dq, ld, acc, qt * 16, L, scr, lane, rs[qt]);
     if (dbias) add_rounded(csum, acc);           // rows past L are exact zeros (their dS is)
   }
   if (dbias) store_colsum(dbias, csum, lane);
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
           acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane),
                                                            cat4(b16[2 * ks], b16[2 * ks + 1]), acc[dt], 0, 0, 0);
       }
-      store_rows(pass == 0 ? dv : dk, ld, acc, kt * 16, L, scr, lane);
+      store_rows(pass == 0 ? dv : dk, ld, acc, kt * 16, L, scr, lane, rs[kt]);
       if (dbias) add_rounded(csum, acc);         // keys past L are exact zeros (P and dS are)
       __builtin_amdgcn_sched_barrier(0);         // one key tile at a time: the scheduler would otherwise hoist every tile's MFMAs
     }
@@ -332,8 +335,26 @@ extern "C" int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, in
   return hmmc_launch_status();
 }
 
+static int attention_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, float* dbias_partial,
+                         const float* rowstat, int nseq, int L, int H, int causal, hipStream_t stream);
+
 extern "C" int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
                                       float* dbias_partial, int nseq, int L, int H, int causal, hipStream_t stream) {
+  return attention_bwd(qkv, out, lse, dout, dqkv, dbias_partial, nullptr, nseq, L, H, causal, stream);
+}
+
+// the same with every row of dqkv multiplied by rowstat[token][0] on its way out (sequences of at most 64 tokens): the
+// gradient a folded ln_1 -> in_proj consumes (ln_fold.hip); dbias_partial stays the column sums of the unscaled gradient
+extern "C" int hmmc_attention_f16_bwd_scaled(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
+                                             float* dbias_partial, const float* rowstat, int nseq, int L, int H, int causal,
+                                             hipStream_t stream) {
+  if (!rowstat) return HMMC_ERR_ARG;
+  if (L > 64) return HMMC_ERR_UNSUPPORTED;
+  return attention_bwd(qkv, out, lse, dout, dqkv, dbias_partial, rowstat, nseq, L, H, causal, stream);
+}
+
+static int attention_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, float* dbias_partial,
+                         const float* rowstat, int nseq, int L, int H, int causal, hipStream_t stream) {
   if (!qkv || !out || !lse || !dout || !dqkv || nseq <= 0 || L <= 0 || H <= 0) return HMMC_ERR_ARG;
   if (L > 256) return HMMC_ERR_UNSUPPORTED;
   if (L > 64) {
@@ -344,7 +365,7 @@ extern "C" int hmmc_attention_f16_bwd(const void* qkv, const void* out, const fl
   }
   AttnArgs p{};
   p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = (float*)lse; p.dout = (const half_t*)dout;
-  p.dqkv = (half_t*)dqkv; p.dbias = dbias_partial; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
+  p.dqkv = (half_t*)dqkv; p.dbias = dbias_partial; p.rowstat = rowstat; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   long pairs = (long)nseq * H;
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
   if (L <= 32) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, 4 * ((32 + 16) * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);

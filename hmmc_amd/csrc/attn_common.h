@@ -7,6 +7,8 @@ struct HmmcAttnArgs {
   const half_t* qkv; half_t* out; float* lse;
   const half_t* dout; half_t* dqkv;
   float* dbias;                 // optional [nseq][3D]: per-sequence column sums of dqkv (in_proj bias gradient partials)
+  const float* rowstat;         // optional [nseq * L][2]: the backward writes rowstat[token][0] x dqkv[token][:] (the rstd of a folded
+                                // ln_1, ln_fold.hip); the bias partials stay those of the unscaled gradient
   int nseq, L, H, causal;
 };
 typedef HmmcAttnArgs AttnArgs;
@@ -47,13 +49,15 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 // strip goes through a 16 x 144 B LDS scratch (8-byte writes from the MFMA layout, 16-byte reads in lane order) so that
 // every store instruction writes 8 full 128-byte rows with consecutive lanes on consecutive bytes; a wave's LDS
 // operations execute in order, so strips follow each other without a wait.
-__device__ __forceinline__ void store_rows(half_t* dst, long ld, const f4 (&acc)[4], int row0, int L, half_t* scr, int lane) {
+// scale: a factor for this lane's row (row0 + c), applied to the value stored only.
+__device__ __forceinline__ void store_rows(half_t* dst, long ld, const f4 (&acc)[4], int row0, int L, half_t* scr, int lane,
+                                           float scale = 1.0f) {
   const int g = lane >> 4, c = lane & 15;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     h4 v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (half_t)acc[dt][r];
+    for (int r = 0; r < 4; ++r) v[r] = (half_t)(acc[dt][r] * scale);
     *reinterpret_cast<h4*>(scr + c * LDS_STRIDE + dt * 16 + 4 * g) = v;
   }
 #pragma unroll

@@ -43,7 +43,8 @@ constexpr int BKT = 64;
 
 enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32, EPI_SAVE_DGELU = 64, EPI_MULAUX = 128,
        EPI_LNFOLD = 256,      // acc -> a_r * acc + (b_r * c_n + d_n): LayerNorm folded into the GEMM (rowstat, colterms), see below
-       EPI_ROWSTAT = 512 };   // + per-row (sum, sum of squares) of the fp16 values written, one pair per 64-column block (stat_part)
+       EPI_ROWSTAT = 512,     // + per-row (sum, sum of squares) of the fp16 values written, one pair per 64-column block (stat_part)
+       EPI_ROWSCALE = 1024 }; // out *= rowstat[m][0] (the row's rstd) as the last step: the backward of a folded LayerNorm (ln_fold.hip)
 
 struct GemmArgs {
   const half_t* A; const half_t* B; half_t* C;
@@ -224,13 +225,15 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
   // (c_n, d_n) of its 16 columns are requested up front.
   f4 fold_c[4], fold_d[4];
   f2 fold_r[MT];
-  if (flags & EPI_LNFOLD) {
+  if (flags & (EPI_LNFOLD | EPI_ROWSCALE)) {
+    if (flags & EPI_LNFOLD) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 16 * j + 4 * g;
-      const int nn = (FULL || n < p.N) ? n : 0;
-      fold_c[j] = *reinterpret_cast<const f4*>(p.colterms + nn);
-      fold_d[j] = *reinterpret_cast<const f4*>(p.colterms + p.N + nn);
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 16 * j + 4 * g;
+        const int nn = (FULL || n < p.N) ? n : 0;
+        fold_c[j] = *reinterpret_cast<const f4*>(p.colterms + nn);
+        fold_d[j] = *reinterpret_cast<const f4*>(p.colterms + p.N + nn);
+      }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -365,6 +368,15 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
       } else {
         out = v;
       }
+      if (flags & EPI_ROWSCALE) {
+        // the column sums (bias gradient) are of the UNSCALED values, rounded to fp16 as the unfolded path stores them; the
+        // tensor written is rstd_r x the gradient, which is what the folded weight gradient and LayerNorm backward consume
+        if (want_csum && (FULL || m_base + 16 * i + c < p.M)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) csum[j][r] += r16(out[r]);
+        }
+        out = out * fold_r[i][0];
+      }
       const unsigned lo = pk2(out[0], out[1]), hi = pk2(out[2], out[3]);
       pc[j] = u2{lo, hi};
       if (flags & EPI_ROWSTAT) {
@@ -378,7 +390,7 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
         rs2 = __builtin_amdgcn_fdot2(hh, hh, rs2, false);
       }
     }
-    if (want_csum) {                               // sums of the ROUNDED values, as a pass over the stored tensor would see
+    if (want_csum && !(flags & EPI_ROWSCALE)) {    // sums of the ROUNDED values, as a pass over the stored tensor would see
       const bool row_ok = FULL || m_base + 16 * i + c < p.M;
       if (row_ok) {
 #pragma unroll
@@ -820,7 +832,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_wgrad_group_kernel(GemmArgs p
 }
 
 // the slabs of a grouped launch -> the fp16 results: problem j, element e of its [M_j][N_j]
-struct GroupOut { half_t* C[GROUP_MAX]; long slab_off[GROUP_MAX]; long elems[GROUP_MAX + 1]; int N[GROUP_MAX], ldc[GROUP_MAX]; int n, S; };
+// C32[j] != nullptr: problem j leaves as fp32 sums [M_j][N_j] (dense) instead of fp16: the folded weight gradients, which are
+// corrected and scaled by gamma afterwards (ln_fold.hip: fold_grad_finish)
+struct GroupOut { half_t* C[GROUP_MAX]; float* C32[GROUP_MAX]; long slab_off[GROUP_MAX]; long elems[GROUP_MAX + 1]; int N[GROUP_MAX], ldc[GROUP_MAX]; int n, S; };
 __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* __restrict__ ws, GroupOut go) {
   const long total4 = go.elems[go.n] / 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -832,6 +846,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* _
     const float* src = ws + go.slab_off[j] + le;
     f4 s = *reinterpret_cast<const f4*>(src);
     for (int k = 1; k < go.S; ++k) s += *reinterpret_cast<const f4*>(src + k * slab);
+    if (go.C32[j]) { *reinterpret_cast<f4*>(go.C32[j] + le) = s; continue; }
     const int m = (int)(le / go.N[j]), n = (int)(le - (long)m * go.N[j]);
     h4 o;
 #pragma unroll
@@ -924,12 +939,16 @@ void launch_cfg(const GemmArgs& p, bool ak, bool bk, dim3 grid, hipStream_t stre
         return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS | EPI_QGELU | EPI_SAVE_DGELU>(p, grid, stream);
       case EPI_LNFOLD: return launch_one<true, true, BM, BN, WM, WN, EPI_LNFOLD>(p, grid, stream);
       case EPI_LNFOLD | EPI_QGELU: return launch_one<true, true, BM, BN, WM, WN, EPI_LNFOLD | EPI_QGELU>(p, grid, stream);
+      case EPI_LNFOLD | EPI_QGELU | EPI_SAVE_DGELU:
+        return launch_one<true, true, BM, BN, WM, WN, EPI_LNFOLD | EPI_QGELU | EPI_SAVE_DGELU>(p, grid, stream);
       case EPI_BIAS | EPI_RESID | EPI_ROWSTAT: return launch_one<true, true, BM, BN, WM, WN, EPI_BIAS | EPI_RESID | EPI_ROWSTAT>(p, grid, stream);
       default: return launch_one<true, true, BM, BN, WM, WN, -1>(p, grid, stream);
     }
   } else if (ak && !bk) {         // dgrad: dx = dy W
     if (f == 0) return launch_one<true, false, BM, BN, WM, WN, 0>(p, grid, stream);
     if (p.csum && (p.flags & ~EPI_COLSUM) == EPI_MULAUX) return launch_one<true, false, BM, BN, WM, WN, EPI_MULAUX | EPI_COLSUM>(p, grid, stream);
+    if (p.csum && (p.flags & ~EPI_COLSUM) == (EPI_MULAUX | EPI_ROWSCALE))
+      return launch_one<true, false, BM, BN, WM, WN, EPI_MULAUX | EPI_COLSUM | EPI_ROWSCALE>(p, grid, stream);
     if (f == EPI_DGELU) return launch_one<true, false, BM, BN, WM, WN, EPI_DGELU>(p, grid, stream);
     return launch_one<true, false, BM, BN, WM, WN, -1>(p, grid, stream);
   } else if (!ak && !bk) {        // wgrad: dW = dy^T x
@@ -1034,9 +1053,11 @@ static int gemm_f16_one(const void* A, const void* B, void* C, int M, int N, int
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return HMMC_ERR_ARG;
   if ((epilogue & EPI_LNFOLD) && (!ex.rowstat || !ex.colterms || (N & 3) || (((uintptr_t)ex.rowstat) & 7) || (((uintptr_t)ex.colterms) & 15)))
     return HMMC_ERR_ARG;
+  if ((epilogue & EPI_ROWSCALE) && (!ex.rowstat || (((uintptr_t)ex.rowstat) & 7))) return HMMC_ERR_ARG;
   if ((epilogue & EPI_ROWSTAT) && (!ex.stat_part || (((uintptr_t)ex.stat_part) & 7))) return HMMC_ERR_ARG;
   if ((epilogue & EPI_ROWSTAT) && (N & 63)) return HMMC_ERR_UNSUPPORTED;             // whole 64-column blocks only
   if ((epilogue & (EPI_LNFOLD | EPI_ROWSTAT)) && !(a_kmajor && b_kmajor)) return HMMC_ERR_UNSUPPORTED;
+  if ((epilogue & EPI_ROWSCALE) && !a_kmajor) return HMMC_ERR_UNSUPPORTED;
   if ((lda & 7) || (ldb & 7) || (ldc & 7) || (N & 7)) return HMMC_ERR_UNSUPPORTED;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)resid | (uintptr_t)aux_in | (uintptr_t)aux_out) & 15) return HMMC_ERR_UNSUPPORTED;
   if ((a_kmajor || b_kmajor) && (K % BKT)) return HMMC_ERR_UNSUPPORTED;   // k tail of a k-major operand
@@ -1151,8 +1172,9 @@ extern "C" size_t hmmc_gemm_f16_wgrad_group_workspace(const int* Np, const int* 
   return (size_t)g.splitk * g.elems * sizeof(float);
 }
 
-extern "C" int hmmc_gemm_f16_wgrad_group(const void* const* dY, const void* const* X, void* const* dW, const int* Np,
-                                         const int* Kp, int nprob, int T, void* workspace, size_t ws_bytes, hipStream_t stream) {
+extern "C" int hmmc_gemm_f16_wgrad_group(const void* const* dY, const void* const* X, void* const* dW, float* const* dW32,
+                                         const int* Np, const int* Kp, int nprob, int T, void* workspace, size_t ws_bytes,
+                                         hipStream_t stream) {
   if (!dY || !X || !dW || !group_ok(Np, Kp, nprob, T)) return HMMC_ERR_UNSUPPORTED;
   const GroupPlan g = group_plan(Np, Kp, nprob, T);
   if (!workspace || ws_bytes < (size_t)g.splitk * g.elems * sizeof(float)) return HMMC_ERR_WORKSPACE;
@@ -1163,7 +1185,9 @@ extern "C" int hmmc_gemm_f16_wgrad_group(const void* const* dY, const void* cons
   long tile0 = 0, off = 0, e0 = 0;
   double flops = 0, bytes = 0;
   for (int j = 0; j < nprob; ++j) {
-    if (!dY[j] || !X[j] || !dW[j] || (((uintptr_t)dY[j] | (uintptr_t)X[j] | (uintptr_t)dW[j]) & 15)) return HMMC_ERR_ARG;
+    float* const w32 = dW32 ? dW32[j] : nullptr;
+    if (!dY[j] || !X[j] || (!dW[j] && !w32) || (((uintptr_t)dY[j] | (uintptr_t)X[j] | (uintptr_t)dW[j] | (uintptr_t)w32) & 15)) return HMMC_ERR_ARG;
+    go.C32[j] = w32;
     GroupProb& q = gp.pr[j];
     q.A = (const half_t*)dY[j]; q.B = (const half_t*)X[j];
     q.lda = Np[j]; q.ldb = Kp[j]; q.M = Np[j]; q.N = Kp[j];
@@ -1212,18 +1236,21 @@ static int gemm_f16_any(const void* A, const void* B, void* C, int M, int N, int
 extern "C" int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                              int a_kmajor, int b_kmajor, const void* bias, const void* resid, void* aux_out,
                              const void* aux_in, int epilogue, void* workspace, size_t ws_bytes, hipStream_t stream) {
-  if (epilogue & (EPI_LNFOLD | EPI_ROWSTAT)) return HMMC_ERR_ARG;      // those take hmmc_gemm_f16_fold's operands
+  if (epilogue & (EPI_LNFOLD | EPI_ROWSTAT | EPI_ROWSCALE)) return HMMC_ERR_ARG;      // those take hmmc_gemm_f16_fold's operands
   return gemm_f16_any(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, resid, aux_out, aux_in, epilogue, workspace, ws_bytes,
                       stream, GemmExtra{nullptr, nullptr, nullptr});
 }
 
-// The forward GEMM with a LayerNorm folded in (HMMC_EPI_LNFOLD: rowstat + colterms) and / or the row statistics of its output
-// emitted for the NEXT folded GEMM (HMMC_EPI_ROWSTAT: stat_part); k-major operands only, operands below 2 GiB.
-extern "C" int hmmc_gemm_f16_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                                  const void* bias, const void* resid, int epilogue, const float* rowstat, const float* colterms,
-                                  float* stat_part, hipStream_t stream) {
-  if (epilogue & ~(EPI_BIAS | EPI_RESID | EPI_QGELU | EPI_LNFOLD | EPI_ROWSTAT)) return HMMC_ERR_UNSUPPORTED;
-  return gemm_f16_any(A, B, C, M, N, K, lda, ldb, ldc, 1, 1, bias, resid, nullptr, nullptr, epilogue, nullptr, 0, stream,
+// hmmc_gemm_f16 (k-major A) with a LayerNorm folded in (HMMC_EPI_LNFOLD: rowstat + colterms), the row statistics of its output
+// emitted for the NEXT folded GEMM (HMMC_EPI_ROWSTAT: stat_part), or its output rows scaled by their rstd (HMMC_EPI_ROWSCALE:
+// rowstat; the data gradient in front of a folded LayerNorm); operands below 2 GiB.
+extern "C" int hmmc_gemm_f16_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int b_kmajor,
+                                  const void* bias, const void* resid, void* aux_out, const void* aux_in, int epilogue,
+                                  const float* rowstat, const float* colterms, float* stat_part, void* workspace, size_t ws_bytes,
+                                  hipStream_t stream) {
+  if (epilogue & ~(EPI_BIAS | EPI_RESID | EPI_QGELU | EPI_SAVE_DGELU | EPI_MULAUX | EPI_COLSUM | EPI_LNFOLD | EPI_ROWSTAT | EPI_ROWSCALE))
+    return HMMC_ERR_UNSUPPORTED;
+  return gemm_f16_any(A, B, C, M, N, K, lda, ldb, ldc, 1, b_kmajor, bias, resid, aux_out, aux_in, epilogue, workspace, ws_bytes, stream,
                       GemmExtra{rowstat, colterms, stat_part});
 }
 
@@ -1236,7 +1263,7 @@ static int gemm_f16_any(const void* A, const void* B, void* C, int M, int N, int
   if (!big_m && !big_k)
     return gemm_f16_one(A, B, C, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, bias, resid, aux_out, aux_in, epilogue, workspace,
                         ws_bytes, stream, 0, nullptr, ex);
-  if (epilogue & (EPI_LNFOLD | EPI_ROWSTAT)) return HMMC_ERR_UNSUPPORTED;
+  if (epilogue & (EPI_LNFOLD | EPI_ROWSTAT | EPI_ROWSCALE)) return HMMC_ERR_UNSUPPORTED;
   const char* a8 = (const char*)A;
   const char* b8 = (const char*)B;
   if (big_m && !big_k) {                         // pieces of whole 256-row tiles; the column-sum partials follow the rows

@@ -150,3 +150,201 @@ extern "C" int hmmc_rowstat_finalize(const float* part, float* stat, int nparts,
   hipLaunchKernelGGL(rowstat_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, part, stat, nparts, rows, 1.0f / D, eps);
   return hmmc_launch_status();
 }
+
+// ---- backward of a folded LayerNorm --------------------------------------------------------------------------------------
+// With y = u W'^T + d, u = (x - mean) rstd, W' = gamma o W (above), the data gradient that reaches the LayerNorm is
+// du = dy W'.  The kernels in front of it hand over dy~ = rstd_r dy[r][:] (HMMC_EPI_ROWSCALE / the scaled attention backward),
+// so the GEMM gives du~ = rstd_r du[r][:] and
+//     dx[r][:] = du~ - mean_k(du~) - u[r][:] mean_k(du~ o u[r][:])  (+ the residual gradient)
+// with no gamma in sight: ln_bwd_fold_kernel.  The weight gradient of the folded layer is taken against the RAW rows,
+//     S[n][k] = sum_r dy~[r][n] x[r][k],    G[n][k] = sum_r dy~[r][n] (x[r][k] - mean_r) = S[n][k] - mean_k S[n][:]
+// (sum_k (x[r][k] - mean_r) = 0, so the mean correction of every row of S is that row's own mean), and
+//     dW = gamma_k G + beta_k db_n,   dgamma_k = sum_n W[n][k] G[n][k],   dbeta_k = sum_n W[n][k] db_n       (db = bias gradient)
+// fold_grad_rowmean_kernel + fold_grad_finish_kernel, once per tower call for all layers.
+namespace {
+
+// structure of ln_bwd_kernel (norm_elem.hip) without gamma, dgamma, dbeta: a wave per row, next row requested early,
+// per-block partial column sums of the dx rows written (the bias gradient of the layer that produced x)
+__global__ __launch_bounds__(256, 4) void ln_bwd_fold_kernel(const half_t* __restrict__ dut, const half_t* __restrict__ x,
+                                                              const float* __restrict__ stat, const half_t* __restrict__ dres,
+                                                              half_t* __restrict__ dx, float* __restrict__ partial, int rows, int D,
+                                                              long in_stride, int want_dxsum) {
+  constexpr int MAXV = 2;                    // D <= 1024
+  __shared__ float sred[4 * 1024];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nchunk = D / 8;
+  const int nwaves = gridDim.x * 4;
+  bool ok[MAXV];
+  int ce[MAXV];
+  float ds[MAXV][8];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    ok[i] = lane + 64 * i < nchunk;
+    ce[i] = ok[i] ? (lane + 64 * i) * 8 : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ds[i][j] = 0.f;
+  }
+  const bool has_res = dres != nullptr;
+  auto load_row = [&](int row, h8 (&tx)[MAXV], h8 (&td)[MAXV], f2& st) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      tx[i] = *reinterpret_cast<const h8*>(x + (long)row * in_stride + ce[i]);
+      td[i] = *reinterpret_cast<const h8*>(dut + (long)row * D + ce[i]);
+    }
+    st = *reinterpret_cast<const f2*>(stat + 2 * (size_t)row);
+  };
+  int row = blockIdx.x * 4 + w;
+  h8 tx[MAXV], td[MAXV], tr[MAXV], nx[MAXV], nd[MAXV];
+  f2 st = f2{0.f, 0.f}, nst;
+  if (row < rows) load_row(row, tx, td, st);
+  for (; row < rows; row += nwaves) {
+    if (has_res) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) tr[i] = *reinterpret_cast<const h8*>(dres + (long)row * in_stride + ce[i]);
+    }
+    load_row(min(row + nwaves, rows - 1), nx, nd, nst);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      if (ok[i]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = (float)td[i][j];
+          const float u = __builtin_fmaf(st[0], (float)tx[i][j], st[1]);
+          s1 += d;
+          s2 += d * u;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / D;
+    s2 = wave_sum(s2) / D;
+    half_t* dxr = dx + (long)row * in_stride;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      h8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float u = __builtin_fmaf(st[0], (float)tx[i][j], st[1]);
+        float val = (float)td[i][j] - s1 - u * s2;
+        if (has_res) val += (float)tr[i][j];
+        o[j] = (half_t)val;
+        if (ok[i]) ds[i][j] += (float)o[j];
+      }
+      if (ok[i]) *reinterpret_cast<h8*>(dxr + ce[i]) = o;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { tx[i] = nx[i]; td[i] = nd[i]; }
+    st = nst;
+  }
+  if (!want_dxsum) return;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (ok[i]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sred[w * 1024 + ce[i] + j] = ds[i][j];
+    }
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < D; col += 256)
+    partial[(long)blockIdx.x * D + col] = sred[col] + sred[1024 + col] + sred[2048 + col] + sred[3072 + col];
+}
+
+constexpr int FIN_MAX = 32;
+struct FinItem { const float* S; const half_t* W; const float* gamma; const float* beta; const half_t* db; half_t* dW; float* dgamma; float* dbeta;
+                 float* vmean; int N, row0, blk0; };
+struct FinArgs { FinItem it[FIN_MAX]; int n, K, rows, blocks; };
+
+// vmean[n] = mean_k S[n][k], one wave per row
+__global__ __launch_bounds__(256) void fold_grad_rowmean_kernel(FinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  int e = 0;
+#pragma unroll 1
+  for (int t = 1; t < a.n; ++t) e = row >= a.it[t].row0 ? t : e;
+  const FinItem& q = a.it[e];
+  const int n = row - q.row0;
+  const float* sr = q.S + (size_t)n * a.K;
+  float s = 0.f;
+  for (int k = lane * 4; k < a.K; k += 256) {
+    const f4 v = *reinterpret_cast<const f4*>(sr + k);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  s = wave_sum(s);
+  if (lane == 0) q.vmean[n] = s / a.K;
+}
+
+// one block per (matrix, 64 columns): thread (column c, row group rg of 4) walks the rows n = rg, rg + 4, ...
+__global__ __launch_bounds__(256) void fold_grad_finish_kernel(FinArgs a) {
+  __shared__ float red[2][4][64];
+  int e = 0;
+#pragma unroll 1
+  for (int t = 1; t < a.n; ++t) e = (int)blockIdx.x >= a.it[t].blk0 ? t : e;
+  const FinItem& q = a.it[e];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int k = ((int)blockIdx.x - q.blk0) * 64 + c;
+  const bool kok = k < a.K;
+  const int kk = kok ? k : 0;
+  const float gm = q.gamma[kk], bt = q.beta[kk];
+  float dg = 0.f, dbt = 0.f;
+  for (int n = rg; n < q.N; n += 4) {
+    const float G = q.S[(size_t)n * a.K + kk] - q.vmean[n];
+    const float dbn = (float)q.db[n];
+    const float w = (float)q.W[(size_t)n * a.K + kk];
+    if (kok) q.dW[(size_t)n * a.K + kk] = (half_t)(gm * G + bt * dbn);
+    dg += w * G;
+    dbt += w * dbn;
+  }
+  red[0][rg][c] = dg;
+  red[1][rg][c] = dbt;
+  __syncthreads();
+  if (rg == 0 && kok) {
+    q.dgamma[k] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    q.dbeta[k] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  }
+}
+
+}  // namespace
+
+static inline int ln_bwd_fold_blocks(int rows) {
+  int nb = (rows + 31) / 32;
+  const int cap = hmmc_num_cus() * 4;                  // = the second __launch_bounds__ argument: one resident round
+  return nb < 1 ? 1 : (nb > cap ? cap : nb);
+}
+// rows of the partial matrix [rows][D] hmmc_layernorm_bwd_fold writes when want_dx_colsum
+extern "C" int hmmc_layernorm_bwd_fold_rows(int rows) { return ln_bwd_fold_blocks(rows); }
+
+// dx[r] = du~[r] - mean(du~[r]) - u[r] mean(du~[r] o u[r]) (+ dres[r]), u = stat[r][0] x[r] + stat[r][1]; x / dres / dx rows at
+// `stride`, du~ compact [rows][D]; partial (when want_dx_colsum): [hmmc_layernorm_bwd_fold_rows(rows)][D] fp32 column sums of dx
+extern "C" int hmmc_layernorm_bwd_fold(const void* dut, const void* x, const float* stat, const void* dres, void* dx, float* partial,
+                                       int want_dx_colsum, int rows, int D, long stride, hipStream_t stream) {
+  if (!dut || !x || !stat || !dx || rows <= 0 || D <= 0 || (want_dx_colsum && !partial)) return HMMC_ERR_ARG;
+  if ((D & 7) || D > 1024 || (stride & 7)) return HMMC_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(ln_bwd_fold_blocks(rows)), dim3(256), 0, stream, (const half_t*)dut, (const half_t*)x, stat,
+                     (const half_t*)dres, (half_t*)dx, partial, rows, D, stride, want_dx_colsum);
+  return hmmc_launch_status();
+}
+
+// The folded weight gradients of up to 32 matrices finished in two launches (HOST arrays of `count` entries): S_e fp32 [N_e][K]
+// (sums against the raw rows), W_e fp16 [N_e][K], gamma_e / beta_e fp32 [K], db_e fp16 [N_e] (the layer's bias gradient) ->
+// dW_e fp16 [N_e][K], dgamma_e / dbeta_e fp32 [K]; vmean_e: fp32 [N_e] scratch.
+extern "C" int hmmc_fold_grad_finish(const float* const* S, const void* const* W, const float* const* gamma, const float* const* beta,
+                                     const void* const* db, void* const* dW, float* const* dgamma, float* const* dbeta,
+                                     float* const* vmean, const int* N, int K, int count, hipStream_t stream) {
+  if (!S || !W || !gamma || !beta || !db || !dW || !dgamma || !dbeta || !vmean || !N || count <= 0 || count > FIN_MAX || K <= 0) return HMMC_ERR_ARG;
+  if (K & 3) return HMMC_ERR_UNSUPPORTED;
+  FinArgs a{};
+  a.n = count; a.K = K;
+  int rows = 0, blocks = 0;
+  const int kb = (K + 63) / 64;
+  for (int e = 0; e < count; ++e) {
+    if (!S[e] || !W[e] || !gamma[e] || !beta[e] || !db[e] || !dW[e] || !dgamma[e] || !dbeta[e] || !vmean[e] || N[e] <= 0) return HMMC_ERR_ARG;
+    a.it[e] = FinItem{S[e], (const half_t*)W[e], gamma[e], beta[e], (const half_t*)db[e], (half_t*)dW[e], dgamma[e], dbeta[e], vmean[e], N[e], rows, blocks};
+    rows += N[e];
+    blocks += kb;
+  }
+  a.rows = rows; a.blocks = blocks;
+  hipLaunchKernelGGL(fold_grad_rowmean_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(fold_grad_finish_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  return hmmc_launch_status();
+}

@@ -35,14 +35,20 @@ int hmmc_attention_f16_fwd(const void*, void*, float*, int, int, int, int, hipSt
 int hmmc_attention_f16_bwd(const void*, const void*, const float*, const void*, void*, float*, int, int, int, int, hipStream_t);
 size_t hmmc_gemm_f16_colsum_rows(int, int, int);
 size_t hmmc_gemm_f16_wgrad_group_workspace(const int*, const int*, int, int);
-int hmmc_gemm_f16_wgrad_group(const void* const*, const void* const*, void* const*, const int*, const int*, int, int, void*, size_t,
-                              hipStream_t);
-int hmmc_gemm_f16_fold(const void*, const void*, void*, int, int, int, int, int, int, const void*, const void*, int, const float*,
-                       const float*, float*, hipStream_t);
+int hmmc_gemm_f16_wgrad_group(const void* const*, const void* const*, void* const*, float* const*, const int*, const int*, int, int,
+                              void*, size_t, hipStream_t);
+int hmmc_gemm_f16_fold(const void*, const void*, void*, int, int, int, int, int, int, int, const void*, const void*, void*, const void*,
+                       int, const float*, const float*, float*, void*, size_t, hipStream_t);
 int hmmc_ln_fold_prep(const void* const*, const float* const*, const float* const*, const void* const*, void* const*, float* const*,
                       const int*, int, int, hipStream_t);
 int hmmc_rowstat(const void*, float*, int, int, long, float, hipStream_t);
 int hmmc_rowstat_finalize(const float*, float*, int, int, int, float, hipStream_t);
+int hmmc_attention_f16_bwd_scaled(const void*, const void*, const float*, const void*, void*, float*, const float*, int, int, int, int,
+                                  hipStream_t);
+int hmmc_layernorm_bwd_fold_rows(int);
+int hmmc_layernorm_bwd_fold(const void*, const void*, const float*, const void*, void*, float*, int, int, int, long, hipStream_t);
+int hmmc_fold_grad_finish(const float* const*, const void* const*, const float* const*, const float* const*, const void* const*,
+                          void* const*, float* const*, float* const*, float* const*, const int*, int, int, hipStream_t);
 int hmmc_temporal_attention_fwd(const float*, float*, float*, int, int, int, int, hipStream_t);
 int hmmc_temporal_attention_bwd(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
 }
@@ -50,7 +56,7 @@ int hmmc_temporal_attention_bwd(const float*, const float*, const float*, float*
 namespace {
 
 enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_QGELU = 4, EPI_DGELU = 8, EPI_COLSUM = 32, EPI_SAVE_DGELU = 64, EPI_MULAUX = 128,
-       EPI_LNFOLD = 256, EPI_ROWSTAT = 512 };
+       EPI_LNFOLD = 256, EPI_ROWSTAT = 512, EPI_ROWSCALE = 1024 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -253,15 +259,22 @@ extern "C" int hmmc_tower_fwd(const void* x, void* y, const void* const* params,
 // Per layer: [3D + 4D][D] fp16 folded weights + [2][3D + 4D] fp32 column terms; shared: the row pairs [T][2] and the
 // per-64-column partial statistics [D / 64][T][2] of the residual stream (see ln_fold.hip).
 namespace {
-struct FoldLayer { char *w1, *w2; float *cd1, *cd2; };
+// s1 / s2 / vm (training only): fp32 weight-gradient sums of in_proj / c_fc against the raw rows and the row-mean scratch of
+// hmmc_fold_grad_finish
+struct FoldLayer { char *w1, *w2; float *cd1, *cd2, *s1, *s2, *vm; };
 struct FoldWs { float *stat, *part; size_t per_layer, bytes; };
-FoldWs fold_carve(char* base, long T, int D, int nlayers, FoldLayer* out) {
+FoldWs fold_carve(char* base, long T, int D, int nlayers, int train, FoldLayer* out) {
   FoldWs f;
   const size_t w1 = al((size_t)3 * D * D * 2), w2 = al((size_t)4 * D * D * 2), c1 = al((size_t)2 * 3 * D * 4), c2 = al((size_t)2 * 4 * D * 4);
-  f.per_layer = w1 + w2 + c1 + c2;
+  const size_t g1 = train ? al((size_t)3 * D * D * 4) : 0, g2 = train ? al((size_t)4 * D * D * 4) : 0, vm = train ? al((size_t)7 * D * 4) : 0;
+  f.per_layer = w1 + w2 + c1 + c2 + g1 + g2 + vm;
   char* p = base;
   for (int i = 0; i < nlayers; ++i) {
-    if (out) { out[i].w1 = p; out[i].w2 = p + w1; out[i].cd1 = (float*)(p + w1 + w2); out[i].cd2 = (float*)(p + w1 + w2 + c1); }
+    if (out) {
+      out[i].w1 = p; out[i].w2 = p + w1; out[i].cd1 = (float*)(p + w1 + w2); out[i].cd2 = (float*)(p + w1 + w2 + c1);
+      out[i].s1 = (float*)(p + w1 + w2 + c1 + c2); out[i].s2 = (float*)(p + w1 + w2 + c1 + c2 + g1);
+      out[i].vm = (float*)(p + w1 + w2 + c1 + c2 + g1 + g2);
+    }
     p += f.per_layer;
   }
   f.stat = (float*)p; p += al((size_t)T * 2 * 4);
@@ -269,66 +282,114 @@ FoldWs fold_carve(char* base, long T, int D, int nlayers, FoldLayer* out) {
   f.bytes = (size_t)(p - base);
   return f;
 }
+// layers of a training call that run folded: all but the last when the caller keeps that one on the unfolded kernels
+inline int nfold_of(int nlayers, int last_exact) { return last_exact ? nlayers - 1 : nlayers; }
 }  // namespace
 
-extern "C" size_t hmmc_tower_fold_bytes(long tokens, int D, int nlayers) { return fold_carve(nullptr, tokens, D, nlayers, nullptr).bytes; }
+// train = 1: the workspace also holds what hmmc_tower_bwd_fold needs (fp32 weight-gradient sums); it must then live from the
+// forward call to the backward call (the folded weights in it are operands of the backward's data gradients)
+extern "C" size_t hmmc_tower_fold_bytes(long tokens, int D, int nlayers, int train) {
+  return fold_carve(nullptr, tokens, D, nlayers, train, nullptr).bytes;
+}
 
-// y = tower(x) for an fp16 tower whose activations are not kept (eval, momentum encoders), ln_1 / ln_2 folded into in_proj /
-// c_fc: the same blocks as hmmc_tower_fwd (modules/module_clip.py:231-257) without the four LayerNorm passes over the
-// residual stream per layer.  acts: ONE slab of hmmc_tower_act_bytes(); fold_ws: hmmc_tower_fold_bytes(); x_stat (optional):
-// the row pairs (rstd, -rstd mean) [tokens][2] of x when its producer already has them (hmmc_vit_embed_ln).
-extern "C" int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y, const void* const* params, void* acts, int nseq, int L,
-                                    int heads, int D, int nlayers, int causal, float eps, int lead_only, void* fold_ws,
-                                    size_t fold_bytes, hipStream_t s) {
+// y = tower(x) for an fp16 tower with ln_1 / ln_2 folded into in_proj / c_fc: the same blocks as hmmc_tower_fwd
+// (modules/module_clip.py:231-257) without the four LayerNorm passes over the residual stream per layer.
+// keep_acts = 0 (eval, momentum encoders): acts is ONE slab of hmmc_tower_act_bytes(), fold_ws = hmmc_tower_fold_bytes(.., 0).
+// keep_acts = 1 (training; hmmc_tower_bwd_fold takes the same acts and fold_ws): acts holds nlayers slabs, the folded layers'
+// row statistics are kept in their slabs' mean / rstd slots, c_fc also writes QuickGELU'(h).  last_exact = 1 runs the LAST
+// layer on the unfolded kernels (with lead_only that layer works on 1 / L of the rows: nothing to fold away, and the class-token
+// rows stay bit-identical between a lead_only and an all-token call).  x_stat (optional): the row pairs (rstd, -rstd mean)
+// [tokens][2] of x when its producer already has them (hmmc_vit_embed_ln).
+extern "C" int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y, const void* const* params, void* acts, int keep_acts,
+                                    int nseq, int L, int heads, int D, int nlayers, int causal, float eps, int lead_only, int last_exact,
+                                    void* fold_ws, size_t fold_bytes, hipStream_t s) {
   if (!x || !y || !params || !acts || !fold_ws || nseq <= 0 || L <= 0 || heads <= 0 || nlayers <= 0 || D != heads * 64) return HMMC_ERR_ARG;
   const long T = (long)nseq * L;
   if ((uint64_t)(T + 256) * 4 * D * 2 >= (1ull << 31) - (1ull << 24)) return HMMC_ERR_UNSUPPORTED;     // operands of 2 GiB: hmmc_tower_fwd
+  // training: the scaled attention backward exists for the short kernel only, the folded weight gradients for the grouped launch,
+  // and a lead-only last layer must be the unfolded one
+  if (keep_acts && (L > 64 || group_ws_bytes(T, D) == 0 || (lead_only && !last_exact))) return HMMC_ERR_UNSUPPORTED;
+  const int nfold = nfold_of(nlayers, last_exact);
   std::vector<FoldLayer> fl(nlayers);
-  const FoldWs fw = fold_carve((char*)fold_ws, T, D, nlayers, fl.data());
+  const FoldWs fw = fold_carve((char*)fold_ws, T, D, nlayers, keep_acts, fl.data());
   if (fold_bytes < fw.bytes) return HMMC_ERR_WORKSPACE;
-  // folded weights and column terms of every layer (16 layers = 32 matrices per launch)
-  for (int l0 = 0; l0 < nlayers; l0 += 16) {
+  const size_t slab = hmmc_tower_act_bytes(T, D, nseq, L, heads, 0);
+  // folded weights and column terms of every folded layer (16 layers = 32 matrices per launch)
+  for (int l0 = 0; l0 < nfold; l0 += 16) {
     const void* W[32]; const float* gm[32]; const float* bt[32]; const void* bs[32]; void* Wf[32]; float* cd[32]; int N[32];
     int n = 0;
-    for (int i = l0; i < nlayers && i < l0 + 16; ++i) {
+    for (int i = l0; i < nfold && i < l0 + 16; ++i) {
       const void* const* P = params + (size_t)i * 12;
       W[n] = P[2]; gm[n] = (const float*)P[0]; bt[n] = (const float*)P[1]; bs[n] = P[3]; Wf[n] = fl[i].w1; cd[n] = fl[i].cd1; N[n] = 3 * D; ++n;
       W[n] = P[8]; gm[n] = (const float*)P[6]; bt[n] = (const float*)P[7]; bs[n] = P[9]; Wf[n] = fl[i].w2; cd[n] = fl[i].cd2; N[n] = 4 * D; ++n;
     }
-    CK(hmmc_ln_fold_prep(W, gm, bt, bs, Wf, cd, N, D, n, s));
+    if (n) CK(hmmc_ln_fold_prep(W, gm, bt, bs, Wf, cd, N, D, n, s));
   }
-  // row pairs of the tower's input: given by the kernel that produced x (hmmc_vit_embed_ln), or taken from x here
-  const float* stat0 = x_stat;
-  if (!stat0) { CK(hmmc_rowstat(x, fw.stat, (int)T, D, D, eps, s)); stat0 = fw.stat; }
   const int nparts = D / 64;
   const void* cur = x;
   for (int i = 0; i < nlayers; ++i) {
     const void* const* P = params + (size_t)i * 12;
-    Acts a = carve((char*)acts, T, D, nseq, L, heads, 2, false);
+    Acts a = carve((char*)acts + (keep_acts ? (size_t)i * slab : 0), T, D, nseq, L, heads, 2, false);
     const void* xin = cur;
-    CK(hmmc_gemm_f16_fold(xin, fl[i].w1, a.qkv, (int)T, 3 * D, D, D, D, 3 * D, nullptr, nullptr, EPI_LNFOLD, i == 0 ? stat0 : fw.stat, fl[i].cd1,
-                          nullptr, s));
-    CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
     void* out = y;
-    if (i + 1 < nlayers) out = (void*)(((i & 1) == 0) ? a.x : a.h);
-    if (lead_only && i + 1 == nlayers) {
+    if (i + 1 < nlayers) out = keep_acts ? carve((char*)acts + (size_t)(i + 1) * slab, T, D, nseq, L, heads, 2, false).x
+                                         : (void*)(((i & 1) == 0) ? a.x : a.h);
+    const bool lead = lead_only && i + 1 == nlayers;
+    const int ldl = L * D;
+    if (i >= nfold) {
+      // the last layer on the unfolded kernels (as hmmc_tower_fwd)
+      const int save_epi = EPI_QGELU | (keep_acts ? EPI_SAVE_DGELU : 0);
+      const int R = lead ? nseq : (int)T;                 // rows of the per-token half
+      const int ldr = lead ? ldl : D;                     // their stride in the [T, D] buffers
+      CK(hmmc_layernorm_fwd(xin, (const float*)P[0], (const float*)P[1], a.ln1, a.m1, a.r1, nullptr, (int)T, D, D, eps, 0, s));
+      CK(hmmc_gemm_f16(a.ln1, P[2], a.qkv, (int)T, 3 * D, D, D, D, 3 * D, 1, 1, P[3], nullptr, nullptr, nullptr, EPI_BIAS, nullptr, 0, s));
+      CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+      CK(hmmc_gemm_f16(a.att, P[4], a.x1, R, D, D, ldr, D, ldr, 1, 1, P[5], xin, nullptr, nullptr, EPI_BIAS | EPI_RESID, nullptr, 0, s));
+      CK(hmmc_layernorm_fwd(a.x1, (const float*)P[6], (const float*)P[7], a.ln2, a.m2, a.r2, nullptr, R, D, ldr, eps, 0, s));
+      CK(hmmc_gemm_f16(a.ln2, P[8], a.g, R, 4 * D, D, D, D, 4 * D, 1, 1, P[9], nullptr, keep_acts ? a.h : nullptr, nullptr,
+                       EPI_BIAS | save_epi, nullptr, 0, s));
+      CK(hmmc_gemm_f16(a.g, P[10], out, R, D, 4 * D, 4 * D, 4 * D, ldr, 1, 1, P[11], a.x1, nullptr, nullptr, EPI_BIAS | EPI_RESID, nullptr, 0, s));
+      cur = out;
+      continue;
+    }
+    // row pairs of this layer's input and of x1: in the slab (training: the backward reads them) or in the shared buffer
+    float* const stat1 = keep_acts ? a.m1 : fw.stat;
+    float* const stat2 = keep_acts ? a.m2 : fw.stat;
+    const float* st_in = stat1;
+    if (i == 0) {
+      if (x_stat && !keep_acts) st_in = x_stat;
+      else if (x_stat) { if (hipMemcpyAsync(stat1, x_stat, (size_t)T * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) return HMMC_ERR_LAUNCH; }
+      else CK(hmmc_rowstat(x, stat1, (int)T, D, D, eps, s));
+    }
+    CK(hmmc_gemm_f16_fold(xin, fl[i].w1, a.qkv, (int)T, 3 * D, D, D, D, 3 * D, 1, nullptr, nullptr, nullptr, nullptr, EPI_LNFOLD, st_in, fl[i].cd1,
+                          nullptr, nullptr, 0, s));
+    CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+    const int fc_epi = EPI_LNFOLD | EPI_QGELU | (keep_acts ? EPI_SAVE_DGELU : 0);
+    void* const fc_aux = keep_acts ? a.h : nullptr;
+    if (lead) {
       // the last block's per-token half on the leading rows only, as hmmc_tower_fwd: the same folded arithmetic on rows
       // addressed in place at stride L*D (so a class-token row comes out bit-identical to the all-token pass)
-      const int ldl = L * D;
-      CK(hmmc_gemm_f16_fold(a.att, P[4], a.x1, nseq, D, D, ldl, D, ldl, P[5], xin, EPI_BIAS | EPI_RESID | EPI_ROWSTAT, nullptr, nullptr, fw.part, s));
-      CK(hmmc_rowstat_finalize(fw.part, fw.stat, nparts, nseq, D, eps, s));
-      CK(hmmc_gemm_f16_fold(a.x1, fl[i].w2, a.g, nseq, 4 * D, D, ldl, D, 4 * D, nullptr, nullptr, EPI_LNFOLD | EPI_QGELU, fw.stat, fl[i].cd2, nullptr, s));
+      CK(hmmc_gemm_f16_fold(a.att, P[4], a.x1, nseq, D, D, ldl, D, ldl, 1, P[5], xin, nullptr, nullptr, EPI_BIAS | EPI_RESID | EPI_ROWSTAT, nullptr,
+                            nullptr, fw.part, nullptr, 0, s));
+      CK(hmmc_rowstat_finalize(fw.part, stat2, nparts, nseq, D, eps, s));
+      CK(hmmc_gemm_f16_fold(a.x1, fl[i].w2, a.g, nseq, 4 * D, D, ldl, D, 4 * D, 1, nullptr, nullptr, fc_aux, nullptr, fc_epi, stat2, fl[i].cd2, nullptr,
+                            nullptr, 0, s));
       CK(hmmc_gemm_f16(a.g, P[10], out, nseq, D, 4 * D, 4 * D, 4 * D, ldl, 1, 1, P[11], a.x1, nullptr, nullptr, EPI_BIAS | EPI_RESID, nullptr, 0, s));
       cur = out;
       continue;
     }
-    CK(hmmc_gemm_f16_fold(a.att, P[4], a.x1, (int)T, D, D, D, D, D, P[5], xin, EPI_BIAS | EPI_RESID | EPI_ROWSTAT, nullptr, nullptr, fw.part, s));
-    CK(hmmc_rowstat_finalize(fw.part, fw.stat, nparts, (int)T, D, eps, s));
-    CK(hmmc_gemm_f16_fold(a.x1, fl[i].w2, a.g, (int)T, 4 * D, D, D, D, 4 * D, nullptr, nullptr, EPI_LNFOLD | EPI_QGELU, fw.stat, fl[i].cd2, nullptr, s));
-    const bool more = i + 1 < nlayers;
-    CK(hmmc_gemm_f16_fold(a.g, P[10], out, (int)T, D, 4 * D, 4 * D, 4 * D, D, P[11], a.x1, EPI_BIAS | EPI_RESID | (more ? EPI_ROWSTAT : 0), nullptr,
-                          nullptr, more ? fw.part : nullptr, s));
-    if (more) CK(hmmc_rowstat_finalize(fw.part, fw.stat, nparts, (int)T, D, eps, s));
+    CK(hmmc_gemm_f16_fold(a.att, P[4], a.x1, (int)T, D, D, D, D, D, 1, P[5], xin, nullptr, nullptr, EPI_BIAS | EPI_RESID | EPI_ROWSTAT, nullptr, nullptr,
+                          fw.part, nullptr, 0, s));
+    CK(hmmc_rowstat_finalize(fw.part, stat2, nparts, (int)T, D, eps, s));
+    CK(hmmc_gemm_f16_fold(a.x1, fl[i].w2, a.g, (int)T, 4 * D, D, D, D, 4 * D, 1, nullptr, nullptr, fc_aux, nullptr, fc_epi, stat2, fl[i].cd2, nullptr,
+                          nullptr, 0, s));
+    const bool more = i + 1 < nfold;                      // the next layer is folded too: it needs the row pairs of this output
+    CK(hmmc_gemm_f16_fold(a.g, P[10], out, (int)T, D, 4 * D, 4 * D, 4 * D, D, 1, P[11], a.x1, nullptr, nullptr,
+                          EPI_BIAS | EPI_RESID | (more ? EPI_ROWSTAT : 0), nullptr, nullptr, more ? fw.part : nullptr, nullptr, 0, s));
+    if (more) {
+      float* const next = keep_acts ? carve((char*)acts + (size_t)(i + 1) * slab, T, D, nseq, L, heads, 2, false).m1 : fw.stat;
+      CK(hmmc_rowstat_finalize(fw.part, next, nparts, (int)T, D, eps, s));
+    }
     cur = out;
   }
   return HMMC_OK;
@@ -364,9 +425,46 @@ WgradSync* wgrad_sync_for(hipStream_t s, hipStream_t sw) {
 // stream they run there, beside the dgrad / LayerNorm / attention chain on `s`, and fill the CUs the persistent GEMMs of
 // that chain leave idle in their partial last rounds.  `s` waits for the stream before this call returns control of the
 // gradients (stream order), so the caller sees ordinary single-stream semantics.
+namespace {
+struct FoldBwd { const FoldLayer* fl; int nfold; };     // layers [0, nfold) were run folded by hmmc_tower_fwd_fused(keep_acts = 1)
+}
+static int tower_bwd_impl(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads,
+                          const void* acts, void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal,
+                          int fp32, int lead_only, void* workspace, size_t ws_bytes, hipStream_t wgrad_stream, hipStream_t s,
+                          const FoldBwd* fb);
+
 extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads,
                               const void* acts, void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal,
                               int fp32, int lead_only, void* workspace, size_t ws_bytes, hipStream_t wgrad_stream, hipStream_t s) {
+  return tower_bwd_impl(dy, dx, x0, params, grads, acts, scratch, nseq, L, heads, D, nlayers, causal, fp32, lead_only, workspace, ws_bytes,
+                        wgrad_stream, s, nullptr);
+}
+
+// The backward of hmmc_tower_fwd_fused(keep_acts = 1): same arguments as hmmc_tower_bwd plus the forward's fold_ws and
+// last_exact.  In a folded layer the gradients that reach a LayerNorm arrive scaled by the row's rstd (QuickGELU' dgrad
+// epilogue HMMC_EPI_ROWSCALE, hmmc_attention_f16_bwd_scaled), the data gradients go through the folded weights, the
+// LayerNorm backward needs no gamma (hmmc_layernorm_bwd_fold), the in_proj / c_fc weight gradients are taken against the raw
+// residual stream into fp32 and finished - together with dgamma / dbeta of ln_1 / ln_2 - by ONE hmmc_fold_grad_finish at the
+// end (ln_fold.hip has the algebra).  Needs the grouped weight-gradient path (D % 256 == 0, >= 2048 tokens) and L <= 64.
+extern "C" int hmmc_tower_bwd_fold(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads,
+                                   const void* acts, void* fold_ws, size_t fold_bytes, void* scratch, int nseq, int L, int heads, int D,
+                                   int nlayers, int causal, int lead_only, int last_exact, void* workspace, size_t ws_bytes,
+                                   hipStream_t wgrad_stream, hipStream_t s) {
+  if (!fold_ws || nseq <= 0 || L <= 0 || nlayers <= 0) return HMMC_ERR_ARG;
+  const long T = (long)nseq * L;
+  if (L > 64 || group_ws_bytes(T, D) == 0 || (lead_only && !last_exact)) return HMMC_ERR_UNSUPPORTED;
+  std::vector<FoldLayer> fl(nlayers);
+  const FoldWs fw = fold_carve((char*)fold_ws, T, D, nlayers, 1, fl.data());
+  if (fold_bytes < fw.bytes) return HMMC_ERR_WORKSPACE;
+  FoldBwd fb{fl.data(), nfold_of(nlayers, last_exact)};
+  return tower_bwd_impl(dy, dx, x0, params, grads, acts, scratch, nseq, L, heads, D, nlayers, causal, 0, lead_only, workspace, ws_bytes,
+                        wgrad_stream, s, &fb);
+}
+
+static int tower_bwd_impl(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads,
+                          const void* acts, void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal,
+                          int fp32, int lead_only, void* workspace, size_t ws_bytes, hipStream_t wgrad_stream, hipStream_t s,
+                          const FoldBwd* fb) {
   if (!dy || !dx || !x0 || !params || !grads || !acts || !scratch || nseq <= 0 || L <= 0 || nlayers <= 0 || D != heads * 64)
     return HMMC_ERR_ARG;
   if (lead_only && fp32) return HMMC_ERR_UNSUPPORTED;
@@ -412,6 +510,13 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
                                 gen, s);
     int rc = hmmc_layernorm_bwd_partial(dyp, xp, gm, mean, rstd, dres, dxp, slotp, dx_colsum != nullptr, nullptr, rows, D, stride, dt, s);
     if (rc == 0) defer(slotp, hmmc_layernorm_bwd_rows(rows), (dx_colsum ? 3 : 2) * D, D, dgamma, 1, dbeta, 1, dx_colsum, dt);
+    return rc;
+  };
+  // folded layers: dx = du~ - mean(du~) - u mean(du~ o u) + dres; only the column sums of dx (a bias gradient) are left to reduce
+  auto ln_bwd_folded = [&](const void* dut, const void* xp, const float* stat, const void* dres, void* dxp, void* dx_colsum, int rows,
+                           long stride, float* slotp) -> int {
+    int rc = hmmc_layernorm_bwd_fold(dut, xp, stat, dres, dxp, slotp, dx_colsum != nullptr, rows, D, stride, s);
+    if (rc == 0 && dx_colsum) defer(slotp, hmmc_layernorm_bwd_fold_rows(rows), D, D, dx_colsum, dt);
     return rc;
   };
   hipStream_t sw = wgrad_stream ? wgrad_stream : s;
@@ -463,6 +568,50 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
     if (two && gdone_set[par]) {
       if (hipStreamWaitEvent(s, syncp->gdone[par], 0) != hipSuccess) return HMMC_ERR_LAUNCH;
       gdone_set[par] = false;
+    }
+    if (fb && i < fb->nfold) {
+      // ---- a layer hmmc_tower_fwd_fused ran folded (never a lead-only one: hmmc_tower_bwd_fold checks)
+      const FoldLayer& f = fb->fl[i];
+      const float* const stat1 = a.m1;            // row pairs of the layer's input x
+      const float* const stat2 = a.m2;            // ... and of x1
+      CK(before_overwrite(1));
+      {
+        // dh~ = rstd2_r x [(g_in W_proj) o QuickGELU'(h)], bias partials of the unscaled product
+        const int rows = (int)hmmc_gemm_f16_colsum_rows((int)T, 4 * D, D);
+        CK(hmmc_gemm_f16_fold(g_in, P[10], dh, (int)T, 4 * D, D, D, 4 * D, 4 * D, 0, nullptr, nullptr, nullptr, a.h,
+                              EPI_MULAUX | EPI_COLSUM | EPI_ROWSCALE, stat2, nullptr, nullptr, p_fc, fc_bytes, s));
+        defer(p_fc, rows, 4 * D, 4 * D, G[9], dt);
+      }
+      CK(hmmc_gemm_f16(dh, f.w2, dln, (int)T, D, 4 * D, 4 * D, D, D, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, s));    // du~2
+      CK(before_overwrite(2));
+      CK(ln_bwd_folded(dln, a.x1, stat2, g_in, dx1, G[5], (int)T, D, p_ln2));                   // G[5]: out_proj bias = colsum(dx1)
+      CK(dgrad(f32, dx1, P[4], dln, (int)T, D, D, nullptr, 0, s));                             // datt
+      CK(before_overwrite(3));
+      CK(hmmc_attention_f16_bwd_scaled(a.qkv, a.att, a.stat, dln, dqkv, p_attn, stat1, nseq, L, heads, causal, s));       // rstd1_r x dqkv
+      defer(p_attn, nseq, 3 * D, 3 * D, G[3], dt);
+      {
+        const void* gy[4] = {g_in, dh, dx1, dqkv};
+        const void* gx[4] = {a.g, a.x1, a.att, xin};
+        void* gw[4] = {G[10], nullptr, G[4], nullptr};
+        float* gw32[4] = {nullptr, f.s2, nullptr, f.s1};
+        int Np[4], Kp[4];
+        group_dims(D, Np, Kp);
+        if (two && (hipEventRecord(syncp->ready, s) != hipSuccess || hipStreamWaitEvent(sw, syncp->ready, 0) != hipSuccess)) return HMMC_ERR_LAUNCH;
+        CK(hmmc_gemm_f16_wgrad_group(gy, gx, gw, gw32, Np, Kp, 4, (int)T, two ? wws : workspace, two ? wws_bytes : gen, sw));
+        if (two) {
+          if (hipEventRecord(syncp->gdone[par], sw) != hipSuccess) return HMMC_ERR_LAUNCH;
+          gdone_set[par] = true;
+        }
+      }
+      CK(hmmc_gemm_f16(dqkv, f.w1, dln, (int)T, D, 3 * D, 3 * D, D, D, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, s));   // du~1
+      CK(before_overwrite(0));
+      if (two && gdone_set[par ^ 1]) {
+        if (hipStreamWaitEvent(s, syncp->gdone[par ^ 1], 0) != hipSuccess) return HMMC_ERR_LAUNCH;
+        gdone_set[par ^ 1] = false;
+      }
+      CK(ln_bwd_folded(dln, xin, stat1, dx1, g_out, i > 0 ? grads[(size_t)(i - 1) * 12 + 11] : nullptr, (int)T, D, p_ln1));
+      g_in = g_out;
+      continue;
     }
     if (lead_only && i + 1 == nlayers) {
       // Last block, leading rows only (see hmmc_tower_fwd): g_in = dy and x1 / att are addressed at stride L*D, dh / dln / ln2 /
@@ -519,7 +668,7 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
       int Np[4], Kp[4];
       group_dims(D, Np, Kp);
       if (two && (hipEventRecord(syncp->ready, s) != hipSuccess || hipStreamWaitEvent(sw, syncp->ready, 0) != hipSuccess)) return HMMC_ERR_LAUNCH;
-      CK(hmmc_gemm_f16_wgrad_group(gy, gx, gw, Np, Kp, 4, (int)T, two ? wws : workspace, two ? wws_bytes : gen, sw));
+      CK(hmmc_gemm_f16_wgrad_group(gy, gx, gw, nullptr, Np, Kp, 4, (int)T, two ? wws : workspace, two ? wws_bytes : gen, sw));
       if (two) {
         if (hipEventRecord(syncp->gdone[par], sw) != hipSuccess) return HMMC_ERR_LAUNCH;
         gdone_set[par] = true;
@@ -542,6 +691,25 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
   if (!tasks.empty()) CK(hmmc_multi_colreduce(tasks.data(), (int)tasks.size(), s));
   if (two) {                                     // hand the weight gradients back in `s` order
     if (hipEventRecord(syncp->ready, sw) != hipSuccess || hipStreamWaitEvent(s, syncp->ready, 0) != hipSuccess) return HMMC_ERR_LAUNCH;
+  }
+  if (fb && fb->nfold > 0) {
+    // the folded layers' in_proj / c_fc weight gradients and ln_1 / ln_2 gradients from the fp32 sums against the raw rows: they
+    // need the bias gradients the reduce above just wrote and the sums the weight-gradient stream just handed back
+    for (int l0 = 0; l0 < fb->nfold; l0 += 16) {
+      const float* S[32]; const void* W[32]; const float* gm[32]; const float* bt[32]; const void* db[32]; void* dW[32]; float* dg[32];
+      float* dbt[32]; float* vm[32]; int N[32];
+      int n = 0;
+      for (int i = l0; i < fb->nfold && i < l0 + 16; ++i) {
+        const void* const* P = params + (size_t)i * 12;
+        void* const* G = grads + (size_t)i * 12;
+        const FoldLayer& f = fb->fl[i];
+        S[n] = f.s1; W[n] = P[2]; gm[n] = (const float*)P[0]; bt[n] = (const float*)P[1]; db[n] = G[3]; dW[n] = G[2]; dg[n] = (float*)G[0];
+        dbt[n] = (float*)G[1]; vm[n] = f.vm; N[n] = 3 * D; ++n;
+        S[n] = f.s2; W[n] = P[8]; gm[n] = (const float*)P[6]; bt[n] = (const float*)P[7]; db[n] = G[9]; dW[n] = G[8]; dg[n] = (float*)G[6];
+        dbt[n] = (float*)G[7]; vm[n] = f.vm + 3 * D; N[n] = 4 * D; ++n;
+      }
+      CK(hmmc_fold_grad_finish(S, W, gm, bt, db, dW, dg, dbt, vm, N, D, n, s));
+    }
   }
   return HMMC_OK;
 }

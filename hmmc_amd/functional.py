@@ -173,6 +173,18 @@ def _ptr_array(tensors):
 _FOLD_LN = os.environ.get("HMMC_FOLD_LN", "vit")
 
 
+# The same fold in the TRAINING forward and backward of the frame tower (hmmc_tower_fwd_fused(keep_acts) / hmmc_tower_bwd_fold):
+# no ln_1 / ln_2 pass in either direction's critical data, no normalised activations kept; the tower's last layer stays on the
+# unfolded kernels.  HMMC_FOLD_LN_TRAIN: "vit" (default), "all", "0".
+_FOLD_LN_TRAIN = os.environ.get("HMMC_FOLD_LN_TRAIN", "vit")
+
+
+def fold_train_enabled(tower_default, T, D, L):
+    if _FOLD_LN_TRAIN in ("0", "", "off", False) or not (_FOLD_LN_TRAIN in ("all", "1", True) or tower_default):
+        return False
+    return L <= 64 and D % 256 == 0 and T >= 2048 and (T + 256) * 4 * D * 2 < (1 << 31) - (1 << 24)
+
+
 def fold_enabled(tower_default):
     """tower_default: True for a tower that folds under the default policy (the ViT frame tower)."""
     if _FOLD_LN in ("0", "", "off", False):
@@ -191,12 +203,21 @@ def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep, lead_only
     slab = query("hmmc_tower_act_bytes", T, D, nseq, L, heads, int(fp32))
     acts = torch.empty(slab * (nl if keep else 1), dtype=torch.uint8, device=x.device)
     if fold and not keep and not fp32 and (T + 256) * 4 * D * 2 < (1 << 31) - (1 << 24):
-        fwb = query("hmmc_tower_fold_bytes", T, D, nl)
+        fwb = query("hmmc_tower_fold_bytes", T, D, nl, 0)
         fws = ops.workspace(fwb, x.device, "tower_fold")
         y = torch.empty_like(x)
-        call("hmmc_tower_fwd_fused", ptr(x), ptr(x_stat), ptr(y), _ptr_array(params), ptr(acts), nseq, L, heads, D, nl, int(causal), float(eps),
-             int(lead_only), ptr(fws), fwb)
+        call("hmmc_tower_fwd_fused", ptr(x), ptr(x_stat), ptr(y), _ptr_array(params), ptr(acts), 0, nseq, L, heads, D, nl, int(causal),
+             float(eps), int(lead_only), 0, ptr(fws), fwb)
         return y, None
+    if fold and keep and not fp32:
+        # training: the fold workspace (folded weights, fp32 weight-gradient sums) lives until the backward call
+        last_exact = int(fold == "last_exact")
+        fwb = query("hmmc_tower_fold_bytes", T, D, nl, 1)
+        fws = torch.empty(fwb, dtype=torch.uint8, device=x.device)
+        y = torch.empty_like(x)
+        call("hmmc_tower_fwd_fused", ptr(x), ptr(x_stat), ptr(y), _ptr_array(params), ptr(acts), 1, nseq, L, heads, D, nl, int(causal),
+             float(eps), int(lead_only), last_exact, ptr(fws), fwb)
+        return y, (acts, fws, last_exact)
     wsb = query("hmmc_tower_workspace_bytes", T, D, nseq, int(fp32), 0)
     ws = ops.workspace(wsb, x.device, "tower")
     y = torch.empty_like(x)
@@ -219,6 +240,11 @@ def _tower_backward(dy, x0, params, acts, nseq, L, heads, causal, fp32, lead_onl
     dx = torch.empty_like(x0)
     # weight gradients on their own stream (leaves of the backward): the library orders the two streams itself
     wst = ops.aux_stream(x0.device, "wgrad").cuda_stream if _WGRAD_STREAM else None
+    if isinstance(acts, tuple):                    # a forward that ran folded (hmmc_tower_fwd_fused, keep_acts = 1)
+        acts, fws, last_exact = acts
+        call("hmmc_tower_bwd_fold", ptr(dy), ptr(dx), ptr(x0), _ptr_array(params), _ptr_array(grads), ptr(acts), ptr(fws), fws.numel(),
+             ptr(scratch), nseq, L, heads, D, nl, int(causal), int(lead_only), last_exact, ptr(ws), wsb, wst)
+        return dx, grads
     call("hmmc_tower_bwd", ptr(dy), ptr(dx), ptr(x0), _ptr_array(params), _ptr_array(grads), ptr(acts), ptr(scratch), nseq, L,
          heads, D, nl, int(causal), int(fp32), int(lead_only), ptr(ws), wsb, wst)
     return dx, grads
@@ -229,7 +255,7 @@ class ClipTransformerFn(torch.autograd.Function):
     LayerNorm statistics); the per-layer activations live in a single slab laid out by the library."""
 
     @staticmethod
-    def forward(ctx, x, nseq, L, heads, causal, lead_only, *params):
+    def forward(ctx, x, nseq, L, heads, causal, lead_only, fold, *params):
         keep = any(ctx.needs_input_grad)       # no_grad passes never get here: clip_transformer() below
         x = x.contiguous()
         for prm in params:
@@ -240,7 +266,7 @@ class ClipTransformerFn(torch.autograd.Function):
             raise RuntimeError(f"expected the activations ({x.dtype}) and the tower weights to have the same dtype: after "
                                "model.float() set text_encoder.dtype = torch.float32 as well, as with the reference")
         lead_only = bool(lead_only and not fp32)        # the class-token pruning exists for the fp16 tower only
-        y, acts = _tower_forward(x, params, nseq, L, heads, causal, 1e-5, fp32, keep, lead_only)
+        y, acts = _tower_forward(x, params, nseq, L, heads, causal, 1e-5, fp32, keep, lead_only, fold=fold if keep else False)
         ctx.acts, ctx.x0, ctx.params = acts, (x if keep else None), params
         ctx.cfg = (nseq, L, heads, causal, lead_only, fp32)
         return y
@@ -250,15 +276,15 @@ class ClipTransformerFn(torch.autograd.Function):
         nseq, L, heads, causal, lead_only, fp32 = ctx.cfg
         dx, grads = _tower_backward(dy.contiguous(), ctx.x0, ctx.params, ctx.acts, nseq, L, heads, causal, fp32, lead_only)
         ctx.acts = ctx.x0 = None
-        return (dx, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, None, *grads)
 
 
-def clip_transformer(x, nseq, L, heads, causal, lead_only, *params, x_stat=None, fold=False):
+def clip_transformer(x, nseq, L, heads, causal, lead_only, *params, x_stat=None, fold=False, fold_train=False):
     """ClipTransformerFn.apply, except that passes which record no graph (torch.no_grad(): eval, the momentum encoders of
     modules/modeling.py:347-357) go straight to the forward-only runtime: `ctx.needs_input_grad` reports the inputs'
     requires_grad whatever the grad mode, so until round 4 those passes kept - and wrote - every layer's activations."""
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-        return ClipTransformerFn.apply(x, nseq, L, heads, causal, lead_only, *params)
+        return ClipTransformerFn.apply(x, nseq, L, heads, causal, lead_only, fold_train, *params)
     x = x.contiguous()
     fp32 = x.dtype == torch.float32
     if any(prm.dtype != (x.dtype if prm.dim() == 2 else prm.dtype) for prm in params):

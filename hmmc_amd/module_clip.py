@@ -83,12 +83,16 @@ class Transformer(nn.Module):
             from . import ops
             ops.reserve_cus_for_collectives()
         blocks = list(self.resblocks)
+        train_fold = x.dtype == torch.float16 and Fn.fold_train_enabled(self.fold_ln, x.shape[0], self.width, L)
         for i in range(0, self.layers, per):
             params = []
             for blk in blocks[i:i + per]:
                 params += Fn.block_params(blk)
-            x = Fn.clip_transformer(x, nseq, L, self.heads, self.causal, bool(lead_only and i + per >= self.layers), *params,
-                                    x_stat=x_stat if i == 0 else None, fold=Fn.fold_enabled(self.fold_ln))
+            final = i + per >= self.layers
+            # training fold: every layer but the tower's last (which, lead-only, works on 1 / L of the rows anyway)
+            ft = ("last_exact" if final else "all") if train_fold and not (final and len(params) == Fn.PER_LAYER) else False
+            x = Fn.clip_transformer(x, nseq, L, self.heads, self.causal, bool(lead_only and final), *params,
+                                    x_stat=x_stat if i == 0 else None, fold=Fn.fold_enabled(self.fold_ln), fold_train=ft)
         return x
 
 

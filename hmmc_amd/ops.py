@@ -176,9 +176,53 @@ def gemm_f16_fold(a, b, bias=None, resid=None, epilogue=0, rowstat=None, colterm
     if want_stat:
         part = torch.empty((N // 64, M, 2), dtype=torch.float32, device=a.device)
         epilogue |= EPI_ROWSTAT
-    call("hmmc_gemm_f16_fold", ptr(a), ptr(b), ptr(c), M, N, K, K, K, N, ptr(bias), ptr(resid), epilogue, ptr(rowstat), ptr(colterms),
-         ptr(part))
+    call("hmmc_gemm_f16_fold", ptr(a), ptr(b), ptr(c), M, N, K, K, K, N, 1, ptr(bias), ptr(resid), None, None, epilogue, ptr(rowstat),
+         ptr(colterms), ptr(part), None, 0)
     return (c, part) if want_stat else c
+
+
+def gemm_f16_rowscaled_dgrad(dy, w, aux, rowstat):
+    """rstd_r x [(dy[M,N'] w[N',K']) o aux[M,K']] with the column sums of the unscaled product (EPI_MULAUX | COLSUM | ROWSCALE): the
+    data gradient in front of a folded LayerNorm.  -> (scaled gradient [M,K'], partial column sums fp32 [rows, K'])."""
+    _chk(dy, torch.float16, "dy"); _chk(w, torch.float16, "w"); _chk(aux, torch.float16, "aux"); _chk(rowstat, torch.float32, "rowstat")
+    M, Np = dy.shape
+    Kp = w.shape[1]
+    assert w.shape[0] == Np and tuple(aux.shape) == (M, Kp) and tuple(rowstat.shape) == (M, 2)
+    c = torch.empty((M, Kp), dtype=torch.float16, device=dy.device)
+    rows = query("hmmc_gemm_f16_colsum_rows", M, Kp, Np)
+    part = torch.empty((rows, Kp), dtype=torch.float32, device=dy.device)
+    call("hmmc_gemm_f16_fold", ptr(dy), ptr(w), ptr(c), M, Kp, Np, Np, Kp, Kp, 0, None, None, None, ptr(aux),
+         EPI_MULAUX | EPI_COLSUM | 1024, ptr(rowstat), None, None, ptr(part), part.numel() * 4)
+    return c, part
+
+
+def layernorm_bwd_fold(dut, x, stat, dres=None, want_colsum=False):
+    """dx = du~ - mean(du~) - u mean(du~ o u) (+ dres), u = stat[:, 0] x + stat[:, 1] (include/hmmc_hip.h) [, column sums of dx]"""
+    _chk(dut, torch.float16, "dut"); _chk(x, torch.float16, "x"); _chk(stat, torch.float32, "stat")
+    rows, D = x.shape
+    dx = torch.empty_like(x)
+    part = torch.empty((query("hmmc_layernorm_bwd_fold_rows", rows), D), dtype=torch.float32, device=x.device) if want_colsum else None
+    call("hmmc_layernorm_bwd_fold", ptr(dut), ptr(x), ptr(stat), ptr(dres), ptr(dx), ptr(part), int(want_colsum), rows, D, D)
+    return (dx, part.sum(0)) if want_colsum else dx
+
+
+def fold_grad_finish(items):
+    """items: [(S fp32 [N,K], W fp16 [N,K], gamma, beta fp32 [K], db fp16 [N])] -> [(dW fp16 [N,K], dgamma, dbeta fp32 [K])]"""
+    import ctypes
+    n = len(items)
+    K = items[0][0].shape[1]
+    outs, vms = [], []
+    for S, W, gm, bt, db in items:
+        _chk(S, torch.float32, "S"); _chk(W, torch.float16, "W"); _chk(gm, torch.float32, "gamma"); _chk(bt, torch.float32, "beta")
+        _chk(db, torch.float16, "db")
+        outs.append((torch.empty_like(W), torch.empty(K, dtype=torch.float32, device=W.device), torch.empty(K, dtype=torch.float32, device=W.device)))
+        vms.append(torch.empty(W.shape[0], dtype=torch.float32, device=W.device))
+    P = ctypes.c_void_p * n
+    pa = lambda ts: P(*[t.data_ptr() for t in ts])
+    call("hmmc_fold_grad_finish", pa([i[0] for i in items]), pa([i[1] for i in items]), pa([i[2] for i in items]), pa([i[3] for i in items]),
+         pa([i[4] for i in items]), pa([o[0] for o in outs]), pa([o[1] for o in outs]), pa([o[2] for o in outs]), pa(vms),
+         (ctypes.c_int * n)(*[i[0].shape[0] for i in items]), K, n)
+    return outs
 
 
 def wgrad_group(dys, xs):
@@ -200,7 +244,7 @@ def wgrad_group(dys, xs):
     outs = [torch.empty((dy.shape[1], x.shape[1]), dtype=torch.float16, device=dy.device) for dy, x in zip(dys, xs)]
     P = ctypes.c_void_p * n
     call("hmmc_gemm_f16_wgrad_group", P(*[t.data_ptr() for t in dys]), P(*[t.data_ptr() for t in xs]), P(*[t.data_ptr() for t in outs]),
-         Np, Kp, n, T, ptr(ws), wsb)
+         None, Np, Kp, n, T, ptr(ws), wsb)
     return outs
 
 
@@ -380,12 +424,18 @@ def attention_f16_fwd(qkv, nseq, L, H, causal):
     return out, lse
 
 
-def attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=False):
-    """-> dqkv [, per-sequence column sums of dqkv: fp32 [nseq, 3*64*H] ]"""
+def attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=False, rowstat=None):
+    """-> dqkv [, per-sequence column sums of dqkv: fp32 [nseq, 3*64*H] ]; rowstat [tokens, 2]: row r of dqkv leaves multiplied by
+    rowstat[r, 0] (the bias partials stay unscaled)"""
     _chk(dout, torch.float16, "dout")
     dqkv = torch.empty_like(qkv)
     part = torch.empty((nseq, qkv.shape[1]), dtype=torch.float32, device=qkv.device) if want_dbias else None
-    call("hmmc_attention_f16_bwd", ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), ptr(part), nseq, L, H, int(causal))
+    if rowstat is not None:
+        _chk(rowstat, torch.float32, "rowstat")
+        call("hmmc_attention_f16_bwd_scaled", ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), ptr(part), ptr(rowstat), nseq, L, H,
+             int(causal))
+    else:
+        call("hmmc_attention_f16_bwd", ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), ptr(part), nseq, L, H, int(causal))
     return (dqkv, part) if want_dbias else dqkv
 
 

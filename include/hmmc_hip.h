@@ -45,6 +45,7 @@ typedef void* hmmc_stream_t; /* hipStream_t */
 #define HMMC_EPI_COLSUM 32 /* + fp32 partial column sums of C into `workspace` (see hmmc_gemm_f16_colsum_rows) */
 #define HMMC_EPI_LNFOLD 256  /* hmmc_gemm_f16_fold: acc -> rowstat[m][0] * acc + rowstat[m][1] * colterms[n] + colterms[N + n] */
 #define HMMC_EPI_ROWSTAT 512 /* hmmc_gemm_f16_fold: + (sum, sum of squares) of every output row per 64-column block into stat_part */
+#define HMMC_EPI_ROWSCALE 1024 /* hmmc_gemm_f16_fold: out *= rowstat[m][0] as the last step (column sums stay those of the unscaled values) */
 
 /* fp16 MFMA GEMM, fp32 accumulate: C[M,N] = epilogue(sum_k Aop[m][k] * Bop[n][k]).
  * a_kmajor: Aop[m][k] = A[m*lda + k], else A[k*lda + m]; likewise b_kmajor for B (rows n).
@@ -70,8 +71,10 @@ int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seconds, long* 
  * hmmc_gemm_f16_wgrad_group_workspace returns the workspace bytes, or 0 when the shapes should take one hmmc_gemm_f16 call per
  * gradient instead (dimensions that are not multiples of 256, fewer than 2048 tokens, operands of 2 GiB and more). */
 size_t hmmc_gemm_f16_wgrad_group_workspace(const int* Np, const int* Kp, int nprob, int T);
-int hmmc_gemm_f16_wgrad_group(const void* const* dY, const void* const* X, void* const* dW, const int* Np, const int* Kp,
-                              int nprob, int T, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+/* dW32 (may be NULL; HOST array of nprob device pointers, entries may be NULL): problem j with dW32[j] != NULL leaves as dense
+ * fp32 sums [Np_j][Kp_j] there instead of fp16 in dW[j] - the folded weight gradients that hmmc_fold_grad_finish completes. */
+int hmmc_gemm_f16_wgrad_group(const void* const* dY, const void* const* X, void* const* dW, float* const* dW32, const int* Np,
+                              const int* Kp, int nprob, int T, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
 /* Leave `cus` (0..128, default 0) compute units out of every later hmmc_gemm_f16 grid.  The host sets this once when
  * gradients are all-reduced while the backward pass runs (DistributedDataParallel at main_task_retrieval.py:207, main_pretrain.py:204), so that
  * RCCL's workgroups find free CUs instead of waiting for a persistent GEMM grid to drain.  Process-wide. */
@@ -87,17 +90,34 @@ int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, in
  * rounding), c (sums of the rounded values) and d for `count` <= 32 weight matrices [N_e][K] in one launch (W / gamma / beta /
  * bias / Wf / cd / N are HOST arrays; cd_e is [2][N_e] fp32: c, then d; bias entries may be NULL).  hmmc_rowstat gives the row
  * pairs (rstd_r, -rstd_r mean_r) [rows][2] of fp16 rows; hmmc_rowstat_finalize gives the same from the partial sums a
- * HMMC_EPI_ROWSTAT launch wrote ([nparts = D / 64][rows][2]).  hmmc_gemm_f16_fold is hmmc_gemm_f16 for k-major operands with
- * those operands: HMMC_EPI_LNFOLD (needs rowstat, colterms; bias is inside d) optionally with HMMC_EPI_QGELU; HMMC_EPI_ROWSTAT
- * (needs stat_part, N % 64 == 0) with any of BIAS / RESID.  The rounding points differ from LayerNorm-then-GEMM (gamma o W is
- * rounded instead of LN(x)): hmmc_tower_fwd_fused uses this for forward passes that keep no activations. */
+ * HMMC_EPI_ROWSTAT launch wrote ([nparts = D / 64][rows][2]).  hmmc_gemm_f16_fold is hmmc_gemm_f16 for a k-major A (b_kmajor as
+ * there) with those operands: HMMC_EPI_LNFOLD (needs rowstat, colterms; bias is inside d) optionally with HMMC_EPI_QGELU
+ * [| HMMC_EPI_SAVE_DGELU, aux_out]; HMMC_EPI_ROWSTAT (needs stat_part, N % 64 == 0) with any of BIAS / RESID; HMMC_EPI_ROWSCALE
+ * (needs rowstat) with MULAUX | COLSUM: the data gradient in front of a folded LayerNorm (below).  `workspace` as in
+ * hmmc_gemm_f16 (COLSUM partials).  The rounding points differ from LayerNorm-then-GEMM (gamma o W is rounded instead of
+ * LN(x)): hmmc_tower_fwd_fused uses this for forward passes that keep no activations and, opt-in, for training.
+ *
+ * Backward of a folded layer.  The gradient reaching the LayerNorm is du = dy W'; with dy~ = rstd_r dy[r][:] handed over by
+ * the producer (HMMC_EPI_ROWSCALE, hmmc_attention_f16_bwd_scaled) the data-gradient GEMM gives du~ = rstd_r du and
+ * hmmc_layernorm_bwd_fold computes dx = du~ - mean(du~) - u mean(du~ o u) (+ dres), u = stat[r][0] x + stat[r][1]; its optional
+ * partial [hmmc_layernorm_bwd_fold_rows(rows)][D] holds column sums of dx for hmmc_multi_colreduce.  The weight gradient is
+ * taken against the RAW rows, S = dy~^T x in fp32 (hmmc_gemm_f16_wgrad_group's dW32), and hmmc_fold_grad_finish turns up to
+ * 32 such sums into dW = gamma_k (S - rowmean(S)) + beta_k db_n (fp16), dgamma_k = sum_n W[n][k] (S - rowmean(S))[n][k] and
+ * dbeta_k = sum_n W[n][k] db_n (fp32) - sum_k (x[r][k] - mean_r) = 0 makes each row's mean correction that row's own mean.
+ * HOST arrays of `count` entries; db_e: the layer's fp16 bias gradient [N_e]; vmean_e: fp32 [N_e] scratch. */
 int hmmc_ln_fold_prep(const void* const* W, const float* const* gamma, const float* const* beta, const void* const* bias,
                       void* const* Wf, float* const* cd, const int* N, int K, int count, hmmc_stream_t stream);
 int hmmc_rowstat(const void* x, float* stat, int rows, int D, long stride, float eps, hmmc_stream_t stream);
 int hmmc_rowstat_finalize(const float* part, float* stat, int nparts, int rows, int D, float eps, hmmc_stream_t stream);
-int hmmc_gemm_f16_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, const void* bias,
-                       const void* resid, int epilogue, const float* rowstat, const float* colterms, float* stat_part,
-                       hmmc_stream_t stream);
+int hmmc_gemm_f16_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int b_kmajor,
+                       const void* bias, const void* resid, void* aux_out, const void* aux_in, int epilogue, const float* rowstat,
+                       const float* colterms, float* stat_part, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
+int hmmc_layernorm_bwd_fold_rows(int rows);
+int hmmc_layernorm_bwd_fold(const void* dut, const void* x, const float* stat, const void* dres, void* dx, float* partial,
+                            int want_dx_colsum, int rows, int D, long stride, hmmc_stream_t stream);
+int hmmc_fold_grad_finish(const float* const* S, const void* const* W, const float* const* gamma, const float* const* beta,
+                          const void* const* db, void* const* dW, float* const* dgamma, float* const* dbeta, float* const* vmean,
+                          const int* N, int K, int count, hmmc_stream_t stream);
 
 /* LayerNorm over the last dim (fp32 statistics).  dtype 0: fp16 in/out (CLIP LayerNorm,
  * modules/module_clip.py:217-223, eps 1e-5); dtype 1: fp32 (TF-style LN of the temporal blocks and
@@ -173,6 +193,11 @@ int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, int nseq, int
  * the in-projection bias gradient; the caller finishes with hmmc_colsum over the nseq rows instead of re-reading dqkv. */
 int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
                            float* dbias_partial, int nseq, int L, int H, int causal, hmmc_stream_t stream);
+/* The same (L <= 64) with row r of dqkv multiplied by rowstat[r][0] on its way out - the rstd of a folded ln_1, see
+ * hmmc_gemm_f16_fold; dbias_partial stays the column sums of the unscaled gradient. */
+int hmmc_attention_f16_bwd_scaled(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
+                                  float* dbias_partial, const float* rowstat, int nseq, int L, int H, int causal,
+                                  hmmc_stream_t stream);
 
 /* fp32 MFMA GEMM (exact f32 FMA chain) with general strides: C[m][n] = epi(alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]);
  * one stride of each operand must be 1.  Epilogue flags as hmmc_gemm_f16 plus HMMC_EPI_RELU; QuickGELU is evaluated in fp32.
@@ -314,14 +339,22 @@ size_t hmmc_tower_workspace_bytes(long tokens, int D, int nseq, int fp32, int bw
 int hmmc_tower_fwd(const void* x, void* y, const void* const* params, void* acts, int keep_acts, int nseq, int L, int heads,
                    int D, int nlayers, int causal, float eps, int fp32, int lead_only, void* workspace, size_t ws_bytes,
                    hmmc_stream_t stream);
-/* hmmc_tower_fwd for an fp16 tower whose activations are not kept (eval, the momentum encoders of modules/modeling.py:347-357),
- * with ln_1 / ln_2 folded into in_proj / c_fc (hmmc_gemm_f16_fold above): no LayerNorm pass over the residual stream, the row
- * statistics come out of the out_proj / c_proj epilogues.  acts: ONE slab of hmmc_tower_act_bytes(); fold_ws:
- * hmmc_tower_fold_bytes(); x_stat (may be NULL): the row pairs of x as hmmc_rowstat / hmmc_vit_embed_ln give them.  Returns HMMC_ERR_UNSUPPORTED for operands of 2 GiB and more (use hmmc_tower_fwd). */
-size_t hmmc_tower_fold_bytes(long tokens, int D, int nlayers);
-int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y, const void* const* params, void* acts, int nseq, int L,
-                         int heads, int D, int nlayers, int causal, float eps, int lead_only, void* fold_ws, size_t fold_bytes,
-                         hmmc_stream_t stream);
+/* hmmc_tower_fwd for an fp16 tower with ln_1 / ln_2 folded into in_proj / c_fc (hmmc_gemm_f16_fold above): no LayerNorm pass over
+ * the residual stream, the row statistics come out of the out_proj / c_proj epilogues.  keep_acts = 0 (eval, the momentum
+ * encoders of modules/modeling.py:347-357): acts is ONE slab of hmmc_tower_act_bytes(), fold_ws hmmc_tower_fold_bytes(.., 0).
+ * keep_acts = 1 (training): acts holds nlayers slabs, fold_ws hmmc_tower_fold_bytes(.., 1) and BOTH go to hmmc_tower_bwd_fold;
+ * needs L <= 64, D % 256 == 0, >= 2048 tokens, and last_exact when lead_only.  last_exact = 1: the LAST layer runs on the
+ * unfolded kernels.  x_stat (may be NULL): the row pairs of x as hmmc_rowstat / hmmc_vit_embed_ln give them.  Returns
+ * HMMC_ERR_UNSUPPORTED for operands of 2 GiB and more or shapes outside the above (use hmmc_tower_fwd). */
+size_t hmmc_tower_fold_bytes(long tokens, int D, int nlayers, int train);
+int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y, const void* const* params, void* acts, int keep_acts, int nseq,
+                         int L, int heads, int D, int nlayers, int causal, float eps, int lead_only, int last_exact, void* fold_ws,
+                         size_t fold_bytes, hmmc_stream_t stream);
+/* backward of hmmc_tower_fwd_fused(keep_acts = 1): hmmc_tower_bwd's arguments plus the forward's fold_ws and last_exact */
+int hmmc_tower_bwd_fold(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads, const void* acts,
+                        void* fold_ws, size_t fold_bytes, void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal,
+                        int lead_only, int last_exact, void* workspace, size_t ws_bytes, hmmc_stream_t wgrad_stream,
+                        hmmc_stream_t stream);
 /* wgrad_stream (optional, NULL = `stream`): a second stream for the weight-gradient GEMMs, which are leaves of the backward
  * pass; they then run beside the dgrad / LayerNorm / attention chain.  `stream` waits for it before the call's work is
  * complete in stream order, so callers keep single-stream semantics. */

@@ -182,3 +182,144 @@ def test_vit_embed_ln_is_bit_identical_to_its_two_stages(nframes, L, D):
     c = x0.clone()
     yc, _, _, none = ops.vit_embed_ln_(c, cls, pos, gm, bt, L, want_stat=False, write_x0=False)
     assert none is None and torch.equal(c, x0) and torch.equal(yc, ya)
+
+
+# ----------------------------------------------------------------------------- the fold through the backward pass (training)
+
+def test_rowscaled_dgrad_and_its_bias_partials():
+    """HMMC_EPI_MULAUX | COLSUM | ROWSCALE: rstd_r x [(dy W) o aux] stored, column sums of the UNSCALED fp16-rounded product."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    M, Np, Kp = 4096, 768, 3072
+    dy = (torch.randn(M, Np, device=DEV, generator=g) * 0.1).half()
+    w = (torch.randn(Np, Kp, device=DEV, generator=g) * 0.05).half()
+    aux = torch.rand(M, Kp, device=DEV, generator=g).half()
+    x = (torch.randn(M, 64, device=DEV, generator=g) * 2.0 + 0.5).half()
+    st = ops.rowstat(x)
+    out, part = ops.gemm_f16_rowscaled_dgrad(dy, w, aux, st)
+    base = (dy.double() @ w.double()) * aux.double()
+    ref = base * st[:, :1].double()
+    err = (out.double() - ref).abs()
+    assert (err <= 1.5e-3 * ref.abs() + 1e-4).all(), float((err / (1.5e-3 * ref.abs() + 1e-4)).max())
+    torch.testing.assert_close(part.sum(0).double(), base.half().double().sum(0), rtol=2e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("rows,D", [(4096, 768), (1000, 512), (300, 256)])
+def test_layernorm_backward_folded(rows, D):
+    """dx of hmmc_layernorm_bwd_fold against autograd through (x - mean) rstd with the upstream gradient pre-scaled by rstd."""
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    x = (torch.randn(rows, D, device=DEV, generator=g) * 1.7 + 0.3).half()
+    du = (torch.randn(rows, D, device=DEV, generator=g) * 0.05).half()          # gradient w.r.t. u = (x - mean) rstd
+    dres = (torch.randn(rows, D, device=DEV, generator=g) * 0.05).half()
+    st = ops.rowstat(x)
+    dut = (du.float() * st[:, :1]).half()
+    dx, csum = ops.layernorm_bwd_fold(dut, x, st, dres=dres, want_colsum=True)
+    xd = x.double().requires_grad_()
+    u = (xd - xd.mean(1, keepdim=True)) * torch.rsqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-5)
+    (u * (dut.double() / st[:, :1].double())).sum().backward()
+    ref = xd.grad + dres.double()
+    assert relerr(dx, ref) < 1e-3, relerr(dx, ref)
+    torch.testing.assert_close(csum.double(), dx.double().sum(0), rtol=1e-4, atol=1e-3)
+    dx2 = ops.layernorm_bwd_fold(dut, x, st)
+    assert relerr(dx2, xd.grad) < 1e-3
+
+
+def test_scaled_attention_backward():
+    g = torch.Generator(device=DEV).manual_seed(5)
+    nseq, L, H = 96, 50, 12
+    qkv = torch.randn(nseq * L, 3 * 64 * H, device=DEV, generator=g).half()
+    out, lse = ops.attention_f16_fwd(qkv, nseq, L, H, False)
+    dout = (torch.randn(nseq * L, 64 * H, device=DEV, generator=g) * 0.1).half()
+    st = torch.rand(nseq * L, 2, device=DEV, generator=g) + 0.5
+    d0, p0 = ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, False, want_dbias=True)
+    d1, p1 = ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, False, want_dbias=True, rowstat=st)
+    assert torch.equal(p0, p1)                                                    # bias partials: the unscaled gradient's
+    ref = d0.float() * st[:, :1]
+    err = (d1.float() - ref).abs()
+    assert (err <= 2e-3 * ref.abs() + 1e-6).all()                                 # one more fp16 rounding of the same values
+
+
+def test_fold_grad_finish_against_the_definitions():
+    g = torch.Generator(device=DEV).manual_seed(9)
+    T, N, K = 3000, 2304, 768
+    x = (torch.randn(T, K, device=DEV, generator=g) * 1.5 + 0.4).half()
+    dyt = (torch.randn(T, N, device=DEV, generator=g) * 0.05).half()              # rstd_r x dy
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.04).half()
+    gm = 1.0 + 0.2 * torch.randn(K, device=DEV, generator=g)
+    bt = 0.1 * torch.randn(K, device=DEV, generator=g)
+    db = (torch.randn(N, device=DEV, generator=g) * 0.5).half()
+    S = (dyt.double().t() @ x.double()).float()
+    (dW, dg, dbeta), = ops.fold_grad_finish([(S, W, gm, bt, db)])
+    xc = x.double() - x.double().mean(1, keepdim=True)
+    G = dyt.double().t() @ xc
+    ref_dW = gm.double()[None, :] * G + bt.double()[None, :] * db.double()[:, None]
+    assert relerr(dW, ref_dW) < 1e-3, relerr(dW, ref_dW)
+    torch.testing.assert_close(dg.double(), (W.double() * G).sum(0), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(dbeta.double(), (W.double() * db.double()[:, None]).sum(0), rtol=1e-4, atol=1e-4)
+
+
+def _tower_and_reference(width, heads, L, nseq, layers, causal):
+    from hmmc_amd import module_clip
+    torch.manual_seed(7)
+    tw = module_clip.Transformer(width, layers, heads, attn_mask="causal" if causal else None)
+    for prm in tw.parameters():
+        torch.nn.init.normal_(prm, std=0.04 if prm.dim() > 1 else 0.1)
+    for blk in tw.resblocks:
+        blk.ln_1.weight.data.add_(1.0)
+        blk.ln_2.weight.data.add_(1.0)
+    module_clip.convert_weights(tw)
+    tw = tw.to(DEV)
+    x0 = (torch.randn(nseq * L, width) * 0.7 + 0.1).half().to(DEV)
+    wsel = torch.randn(nseq * L, width).to(DEV) * 0.1
+
+    def fp32_run():
+        P = [[q.detach().double().requires_grad_() for q in Fn.block_params(blk)] for blk in tw.resblocks]
+        xd = x0.double().requires_grad_()
+        h = xd.view(nseq, L, width)
+        mask = torch.full((L, L), float("-inf"), device=DEV, dtype=torch.float64).triu_(1) if causal else None
+        for p in P:
+            a = torch.nn.functional.layer_norm(h, (width,), p[0], p[1], 1e-5)
+            qkv = a @ p[2].t() + p[3]
+            q, k, v = [t.view(nseq, L, heads, 64).transpose(1, 2) for t in qkv.chunk(3, -1)]
+            s_ = (q @ k.transpose(-1, -2)) / 8.0
+            if mask is not None:
+                s_ = s_ + mask
+            o = (s_.softmax(-1) @ v).transpose(1, 2).reshape(nseq, L, width)
+            h = h + o @ p[4].t() + p[5]
+            a = torch.nn.functional.layer_norm(h, (width,), p[6], p[7], 1e-5)
+            f = a @ p[8].t() + p[9]
+            h = h + (f * torch.sigmoid(1.702 * f)) @ p[10].t() + p[11]
+        (h.reshape(nseq * L, width) * wsel.double()).sum().backward()
+        return h.reshape(nseq * L, width).detach(), xd.grad, [[q.grad for q in p] for p in P]
+    return tw, x0, wsel, fp32_run
+
+
+@pytest.mark.parametrize("width,heads,L,nseq,layers,causal", [(256, 4, 10, 210, 3, False), (768, 12, 50, 64, 3, False), (512, 8, 32, 96, 2, True)])
+def test_folded_training_tower_against_fp32_autograd(width, heads, L, nseq, layers, causal, monkeypatch):
+    """hmmc_tower_fwd_fused(keep_acts) + hmmc_tower_bwd_fold: output, input gradient and EVERY parameter gradient against fp64
+    autograd through the same blocks - as close as the unfolded kernels are (x 1.5), tensor by tensor."""
+    tw, x0, wsel, fp32_run = _tower_and_reference(width, heads, L, nseq, layers, causal)
+    yr, dxr, gr = fp32_run()
+    monkeypatch.setattr(Fn, "_FOLD_LN_TRAIN", "vit")            # the tower's own flag decides (fold_ln below)
+    res = {}
+    for fold in (False, True):
+        tw.fold_ln = fold
+        for prm in tw.parameters():
+            prm.grad = None
+        x = x0.clone().requires_grad_()
+        y = tw(x, nseq, L)
+        (y.float() * wsel).sum().backward()
+        res[fold] = (y.detach(), x.grad, [[q.grad for q in Fn.block_params(blk)] for blk in tw.resblocks])
+    assert not torch.equal(res[True][0], res[False][0]), "the folded kernels did not run"
+    names = ["ln_1.w", "ln_1.b", "in_proj.w", "in_proj.b", "out_proj.w", "out_proj.b", "ln_2.w", "ln_2.b", "c_fc.w", "c_fc.b", "c_proj.w", "c_proj.b"]
+    e0, e1 = relerr(res[False][0], yr), relerr(res[True][0], yr)
+    assert e1 <= 1.5 * e0 + 1e-4, ("y", e1, e0)
+    e0, e1 = relerr(res[False][1], dxr), relerr(res[True][1], dxr)
+    print(f"dx: unfolded {e0:.3e} folded {e1:.3e}")
+    assert e1 <= 1.5 * e0 + 2e-3, ("dx", e1, e0)
+    worst = []
+    for li in range(layers):
+        for j, nm in enumerate(names):
+            a0, a1 = relerr(res[False][2][li][j], gr[li][j]), relerr(res[True][2][li][j], gr[li][j])
+            worst.append((a1 / max(a0, 1e-4), f"layer {li} {nm}", a0, a1))
+            assert a1 <= 2.0 * a0 + 3e-3, (li, nm, a1, a0)
+    print("worst ratios:", sorted(worst, reverse=True)[:4])
