@@ -24,6 +24,7 @@ SIGNATURES = {
     "hmmc_layernorm_bwd_fold_rows": ("i", "i"),
     "hmmc_layernorm_bwd_fold": ("ppppppiiilp", "i"),
     "hmmc_fold_grad_finish": ("ppppppppppiip", "i"),
+    "hmmc_fold_grad_scratch_floats": ("ii", "z"),
     "hmmc_attention_f16_bwd_scaled": ("pppppppiiiip", "i"),
     "hmmc_tower_bwd_fold": ("pppppppzpiiiiiiiipzpp", "i"),
     "hmmc_ln_fold_prep": ("pppppppiip", "i"),

@@ -223,23 +223,54 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
   // normalised activations are never written or read (reference modules/module_clip.py:217-223,252-256: ln_1 -> in_proj,
   // ln_2 -> c_fc).  The row pair (a_r, b_r) = (rstd_r, -rstd_r mean_r) of each of this lane's MT rows and the column pairs
   // (c_n, d_n) of its 16 columns are requested up front.
+  // Registers: the MT row pairs would be 2 MT live registers through the whole strip loop (with the second QuickGELU output
+  // that took the kernel over its 256: scratch spills sit in the K loop's in-order vmcnt queue).  The LNFOLD kernels have no
+  // residual / auxiliary operand, so their operand tile in LDS is free: the pairs are parked there (16 rows per strip, lanes
+  // g = 0 write, every lane reads its row back per strip; a wave's LDS operations execute in order).  ROWSCALE (which does
+  // use the operand tile) needs the rstd alone: MT registers.
   f4 fold_c[4], fold_d[4];
-  f2 fold_r[MT];
-  if (flags & (EPI_LNFOLD | EPI_ROWSCALE)) {
-    if (flags & EPI_LNFOLD) {
+  float fold_a[MT];
+  // 256x256 kernels built for LNFOLD: the K loop brought the wave's 128 row pairs (1 KiB) and 64 column pairs (c | d, 512 B) into
+  // that tile by LDS-DMA during the item's last K-tile (gemm_f16_body): no global-memory latency in front of strip 0
+  constexpr bool FOLD_PRE = MT == 8 && F >= 0 && (F & EPI_LNFOLD) != 0;
+  if (FOLD_PRE) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + 16 * j + 4 * g;
-        const int nn = (FULL || n < p.N) ? n : 0;
-        fold_c[j] = *reinterpret_cast<const f4*>(p.colterms + nn);
-        fold_d[j] = *reinterpret_cast<const f4*>(p.colterms + p.N + nn);
-      }
+    for (int j = 0; j < 4; ++j) {
+      fold_c[j] = *reinterpret_cast<const f4*>(scr + 2048 + 1024 + (16 * j + 4 * g) * 4);
+      fold_d[j] = *reinterpret_cast<const f4*>(scr + 2048 + 1280 + (16 * j + 4 * g) * 4);
     }
+  } else if (flags & EPI_LNFOLD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 16 * j + 4 * g;
+      const int nn = (FULL || n < p.N) ? n : 0;
+      fold_c[j] = *reinterpret_cast<const f4*>(p.colterms + nn);
+      fold_d[j] = *reinterpret_cast<const f4*>(p.colterms + p.N + nn);
+    }
+    f2 t[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = FULL ? m_base + 16 * i + c : min(m_base + 16 * i + c, p.M - 1);
-      fold_r[i] = *reinterpret_cast<const f2*>(p.rowstat + 2 * (size_t)m);
+      t[i] = *reinterpret_cast<const f2*>(p.rowstat + 2 * (size_t)m);
     }
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) *reinterpret_cast<f2*>(scr + 2048 + (16 * i + c) * 8) = t[i];
+    }
+  }
+  // ROWSCALE: the rstd of strip i's row is requested RS_AHEAD strips early (a register each; all MT up front took this variant,
+  // which already holds four operand strips in flight, over the register file)
+  constexpr int RS_AHEAD = 2;
+  // bounds-checked buffer load (rows past M read 0 and are never stored): ONE lane offset for all strips, the strip is an
+  // immediate - per-strip 64-bit addresses cost two registers each
+  const __amdgpu_buffer_rsrc_t rs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.rowstat, 0, (flags & EPI_ROWSCALE) ? p.M * 8 : 0, 0x00020000);
+  const int rs_off = (m_base + c) * 8;
+  auto load_scale = [&](int i) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_rsrc, rs_off, i * 128, 0));
+  };
+  if (flags & EPI_ROWSCALE) {
+#pragma unroll
+    for (int i = 0; i < RS_AHEAD && i < MT; ++i) fold_a[i] = load_scale(i);
   }
   const bool has_src = flags & (EPI_DGELU | EPI_MULAUX | EPI_RESID);
   const char* src = reinterpret_cast<const char*>((flags & (EPI_DGELU | EPI_MULAUX)) ? p.aux_in : p.resid);
@@ -323,10 +354,13 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
     // pc / qc: the strip's result (and auxiliary result) as packed fp16, four 8-byte pieces in the MFMA layout
     u2 pc[4], qc[4];
     float rs1 = 0.f, rs2 = 0.f;                    // EPI_ROWSTAT: this lane's part of the row's sum and sum of squares
+    if ((flags & EPI_ROWSCALE) && i + RS_AHEAD < MT) fold_a[i + RS_AHEAD] = load_scale(i + RS_AHEAD);
+    f2 fr = f2{1.f, 0.f};                          // EPI_LNFOLD: the row pair of this lane's row of strip i
+    if (flags & EPI_LNFOLD) fr = *reinterpret_cast<const f2*>(scr + 2048 + (16 * i + c) * 8);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f4 v = acc[i][j];
-      if (flags & EPI_LNFOLD) v = fold_r[i][0] * v + (fold_r[i][1] * fold_c[j] + fold_d[j]);
+      if (flags & EPI_LNFOLD) v = fr[0] * v + (fr[1] * fold_c[j] + fold_d[j]);
       if (flags & EPI_BIAS) v += bias[j];
       if (flags & EPI_QGELU) {
         // QuickGELU with the reference's fp16 rounding points, two elements at a time.  The values that torch holds as
@@ -369,13 +403,8 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
         out = v;
       }
       if (flags & EPI_ROWSCALE) {
-        // the column sums (bias gradient) are of the UNSCALED values, rounded to fp16 as the unfolded path stores them; the
-        // tensor written is rstd_r x the gradient, which is what the folded weight gradient and LayerNorm backward consume
-        if (want_csum && (FULL || m_base + 16 * i + c < p.M)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) csum[j][r] += r16(out[r]);
-        }
-        out = out * fold_r[i][0];
+        // the tensor written is rstd_r x the gradient, which is what the folded weight gradient and LayerNorm backward consume
+        out = out * fold_a[i];
       }
       const unsigned lo = pk2(out[0], out[1]), hi = pk2(out[2], out[3]);
       pc[j] = u2{lo, hi};
@@ -390,11 +419,17 @@ __device__ __forceinline__ void epilogue_run(const GemmArgs& p, f4 (&acc)[MT][4]
         rs2 = __builtin_amdgcn_fdot2(hh, hh, rs2, false);
       }
     }
-    if (want_csum && !(flags & EPI_ROWSCALE)) {    // sums of the ROUNDED values, as a pass over the stored tensor would see
+    if (want_csum) {                               // sums of the ROUNDED values, as a pass over the stored tensor would see
       const bool row_ok = FULL || m_base + 16 * i + c < p.M;
       if (row_ok) {
+        // ROWSCALE: the bias gradient is the column sum of the UNSCALED gradient: the stored values divided by the row's factor
+        // again (a second set of packed unscaled values took this variant 30 registers over the file: scratch in the K loop)
+        const float inv = (flags & EPI_ROWSCALE) ? __builtin_amdgcn_rcpf(fold_a[i]) : 1.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) csum[j] += unpack2(pc[j][0], pc[j][1]);
+        for (int j = 0; j < 4; ++j) {
+          if (flags & EPI_ROWSCALE) csum[j] += unpack2(pc[j][0], pc[j][1]) * inv;
+          else csum[j] += unpack2(pc[j][0], pc[j][1]);
+        }
       }
     }
     if (flags & EPI_ROWSTAT) { st1[i] = rs1; st2[i] = rs2; }
@@ -672,9 +707,31 @@ __device__ __forceinline__ void gemm_f16_body(const GemmArgs& p, const GemmGroup
     HMMC_BAR();
     if (wm == 1) HMMC_BAR();
     const int arow = wm * 64, brow = wn * 32;
+    // EPI_LNFOLD: the epilogue's row pairs (this wave's 128 rows: 1 KiB) and column pairs (its 64 columns: c | d, 512 B) arrive
+    // by two LDS-DMA loads issued at the top of the item's LAST K-tile into the operand half of the wave's epilogue scratch
+    // (free in these kernels: no residual / auxiliary operand).  They are older than that K-tile's eight staging loads, so its
+    // closing s_waitcnt vmcnt(8) covers them; its first wait allows the two extra loads in flight (vmcnt(10)).
+    constexpr bool FOLD_PRE = EPI >= 0 && (EPI & EPI_LNFOLD) != 0;
+    __amdgpu_buffer_rsrc_t rrow = ra, rcol = ra;
+    if constexpr (FOLD_PRE) {
+      rrow = __builtin_amdgcn_make_buffer_rsrc((void*)p.rowstat, 0, p.M * 8, 0x00020000);
+      rcol = __builtin_amdgcn_make_buffer_rsrc((void*)p.colterms, 0, p.N * 8, 0x00020000);
+    }
     while (true) {
       const char* base = smem + buf * (4 * HALF);
       h8 af[2][4], b0f[2][2], b1f[2][2];
+      const bool last_kt = FOLD_PRE && kt + 1 >= kt_end;
+      if constexpr (FOLD_PRE) {
+        if (last_kt) {
+          char* const sin = smem + 2 * STAGE_BYTES + wid * EPI_LDS_PER_WAVE + 2048;
+          const unsigned roff = (unsigned)(tm * BM + wm * 128) * 8u + (unsigned)lane * 16u;
+          const int n0w = tn * BN + wn * 64;
+          const unsigned coff = lane < 16 ? (unsigned)(n0w + 4 * lane) * 4u
+                                          : (lane < 32 ? (unsigned)(p.N + n0w + 4 * (lane - 16)) * 4u : 0x80000000u);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rrow, LDS_PTR(sin), 16, roff, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rcol, LDS_PTR(sin + 1024), 16, coff, 0, 0, 0);
+        }
+      }
 #if HMMC_PHASES == 2
       // segment 1
 #pragma unroll
@@ -690,7 +747,8 @@ __device__ __forceinline__ void gemm_f16_body(const GemmArgs& p, const GemmGroup
 #pragma unroll
         for (int j = 0; j < 2; ++j) b1f[ks][j] = read_frag<BK, 128>(base + 3 * HALF, brow + j * 16, ks, lane);
       stage_a(1); s_advance();
-      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      if (last_kt) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       HMMC_BAR();
       HMMC_MM(0, 0, b0f);
       HMMC_MM(0, 2, b1f);
@@ -1051,13 +1109,14 @@ static int gemm_f16_one(const void* A, const void* B, void* C, int M, int N, int
                         const void* aux_in, int epilogue, void* workspace, size_t ws_bytes, hipStream_t stream,
                         int slab_mode, int* slabs_out, const GemmExtra& ex = GemmExtra{nullptr, nullptr, nullptr}) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return HMMC_ERR_ARG;
-  if ((epilogue & EPI_LNFOLD) && (!ex.rowstat || !ex.colterms || (N & 3) || (((uintptr_t)ex.rowstat) & 7) || (((uintptr_t)ex.colterms) & 15)))
+  if ((epilogue & EPI_LNFOLD) && (!ex.rowstat || !ex.colterms || (N & 3) || (((uintptr_t)ex.rowstat) & 15) || (((uintptr_t)ex.colterms) & 15)))
     return HMMC_ERR_ARG;
   if ((epilogue & EPI_ROWSCALE) && (!ex.rowstat || (((uintptr_t)ex.rowstat) & 7))) return HMMC_ERR_ARG;
   if ((epilogue & EPI_ROWSTAT) && (!ex.stat_part || (((uintptr_t)ex.stat_part) & 7))) return HMMC_ERR_ARG;
   if ((epilogue & EPI_ROWSTAT) && (N & 63)) return HMMC_ERR_UNSUPPORTED;             // whole 64-column blocks only
   if ((epilogue & (EPI_LNFOLD | EPI_ROWSTAT)) && !(a_kmajor && b_kmajor)) return HMMC_ERR_UNSUPPORTED;
   if ((epilogue & EPI_ROWSCALE) && !a_kmajor) return HMMC_ERR_UNSUPPORTED;
+  if ((epilogue & EPI_LNFOLD) && (epilogue & (EPI_RESID | EPI_DGELU | EPI_MULAUX))) return HMMC_ERR_UNSUPPORTED;   // share an LDS tile
   if ((lda & 7) || (ldb & 7) || (ldc & 7) || (N & 7)) return HMMC_ERR_UNSUPPORTED;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)resid | (uintptr_t)aux_in | (uintptr_t)aux_out) & 15) return HMMC_ERR_UNSUPPORTED;
   if ((a_kmajor || b_kmajor) && (K % BKT)) return HMMC_ERR_UNSUPPORTED;   // k tail of a k-major operand

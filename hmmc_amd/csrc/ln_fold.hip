@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_fold_kernel(const half_t* __res
 }
 
 constexpr int FIN_MAX = 32;
+constexpr int FIN_SLICES = 8;               // row slices per (matrix, 64 columns): 8 x the blocks, partial dgamma / dbeta per slice
 struct FinItem { const float* S; const half_t* W; const float* gamma; const float* beta; const half_t* db; half_t* dW; float* dgamma; float* dbeta;
                  float* vmean; int N, row0, blk0; };
 struct FinArgs { FinItem it[FIN_MAX]; int n, K, rows, blocks; };
@@ -274,7 +275,9 @@ __global__ __launch_bounds__(256) void fold_grad_rowmean_kernel(FinArgs a) {
   if (lane == 0) q.vmean[n] = s / a.K;
 }
 
-// one block per (matrix, 64 columns): thread (column c, row group rg of 4) walks the rows n = rg, rg + 4, ...
+// one block per (matrix, 64 columns, row slice): thread (column c, row group rg of 4) walks its slice's rows rg, rg + 4, ...
+// eight at a time (eight independent row reads in flight per thread); the slice's dgamma / dbeta parts go to vmean[N + ...]
+// (scratch [N + 2 FIN_SLICES K]) and fold_grad_sum_kernel adds the slices in order.
 __global__ __launch_bounds__(256) void fold_grad_finish_kernel(FinArgs a) {
   __shared__ float red[2][4][64];
   int e = 0;
@@ -282,26 +285,58 @@ __global__ __launch_bounds__(256) void fold_grad_finish_kernel(FinArgs a) {
   for (int t = 1; t < a.n; ++t) e = (int)blockIdx.x >= a.it[t].blk0 ? t : e;
   const FinItem& q = a.it[e];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int k = ((int)blockIdx.x - q.blk0) * 64 + c;
+  const int local = (int)blockIdx.x - q.blk0;
+  const int slice = local % FIN_SLICES;
+  const int k = (local / FIN_SLICES) * 64 + c;
   const bool kok = k < a.K;
   const int kk = kok ? k : 0;
   const float gm = q.gamma[kk], bt = q.beta[kk];
+  const int per = (q.N + FIN_SLICES - 1) / FIN_SLICES;
+  const int n0 = slice * per, n1 = min(q.N, n0 + per);
   float dg = 0.f, dbt = 0.f;
-  for (int n = rg; n < q.N; n += 4) {
-    const float G = q.S[(size_t)n * a.K + kk] - q.vmean[n];
-    const float dbn = (float)q.db[n];
-    const float w = (float)q.W[(size_t)n * a.K + kk];
-    if (kok) q.dW[(size_t)n * a.K + kk] = (half_t)(gm * G + bt * dbn);
-    dg += w * G;
-    dbt += w * dbn;
+  for (int nb = n0 + rg; nb < n1; nb += 32) {
+    float Sv[8], Wv[8], vm[8], dbn[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = min(nb + 4 * u, n1 - 1);
+      Sv[u] = q.S[(size_t)n * a.K + kk];
+      Wv[u] = (float)q.W[(size_t)n * a.K + kk];
+      vm[u] = q.vmean[n];
+      dbn[u] = (float)q.db[n];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = nb + 4 * u;
+      if (n < n1) {
+        const float G = Sv[u] - vm[u];
+        if (kok) q.dW[(size_t)n * a.K + kk] = (half_t)(gm * G + bt * dbn[u]);
+        dg += Wv[u] * G;
+        dbt += Wv[u] * dbn[u];
+      }
+    }
   }
   red[0][rg][c] = dg;
   red[1][rg][c] = dbt;
   __syncthreads();
   if (rg == 0 && kok) {
-    q.dgamma[k] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-    q.dbeta[k] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    float* part = q.vmean + q.N + (size_t)slice * 2 * a.K;
+    part[k] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    part[a.K + k] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
   }
+}
+
+// dgamma / dbeta = the FIN_SLICES partial rows added in slice order (deterministic); one thread per (matrix, column)
+__global__ __launch_bounds__(256) void fold_grad_sum_kernel(FinArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int e = idx / a.K, k = idx - e * a.K;
+  if (e >= a.n) return;
+  const FinItem& q = a.it[e];
+  const float* part = q.vmean + q.N;
+  float g = 0.f, b = 0.f;
+#pragma unroll
+  for (int sl = 0; sl < FIN_SLICES; ++sl) { g += part[(size_t)sl * 2 * a.K + k]; b += part[(size_t)sl * 2 * a.K + a.K + k]; }
+  q.dgamma[k] = g;
+  q.dbeta[k] = b;
 }
 
 }  // namespace
@@ -327,7 +362,9 @@ extern "C" int hmmc_layernorm_bwd_fold(const void* dut, const void* x, const flo
 
 // The folded weight gradients of up to 32 matrices finished in two launches (HOST arrays of `count` entries): S_e fp32 [N_e][K]
 // (sums against the raw rows), W_e fp16 [N_e][K], gamma_e / beta_e fp32 [K], db_e fp16 [N_e] (the layer's bias gradient) ->
-// dW_e fp16 [N_e][K], dgamma_e / dbeta_e fp32 [K]; vmean_e: fp32 [N_e] scratch.
+// dW_e fp16 [N_e][K], dgamma_e / dbeta_e fp32 [K]; vmean_e: fp32 [hmmc_fold_grad_scratch_floats(N_e, K)] scratch.
+extern "C" size_t hmmc_fold_grad_scratch_floats(int N, int K) { return (size_t)N + 2 * (size_t)FIN_SLICES * K; }
+
 extern "C" int hmmc_fold_grad_finish(const float* const* S, const void* const* W, const float* const* gamma, const float* const* beta,
                                      const void* const* db, void* const* dW, float* const* dgamma, float* const* dbeta,
                                      float* const* vmean, const int* N, int K, int count, hipStream_t stream) {
@@ -341,10 +378,11 @@ extern "C" int hmmc_fold_grad_finish(const float* const* S, const void* const* W
     if (!S[e] || !W[e] || !gamma[e] || !beta[e] || !db[e] || !dW[e] || !dgamma[e] || !dbeta[e] || !vmean[e] || N[e] <= 0) return HMMC_ERR_ARG;
     a.it[e] = FinItem{S[e], (const half_t*)W[e], gamma[e], beta[e], (const half_t*)db[e], (half_t*)dW[e], dgamma[e], dbeta[e], vmean[e], N[e], rows, blocks};
     rows += N[e];
-    blocks += kb;
+    blocks += kb * FIN_SLICES;
   }
   a.rows = rows; a.blocks = blocks;
   hipLaunchKernelGGL(fold_grad_rowmean_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(fold_grad_finish_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(fold_grad_sum_kernel, dim3((count * K + 255) / 256), dim3(256), 0, stream, a);
   return hmmc_launch_status();
 }

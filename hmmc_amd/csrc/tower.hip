@@ -266,7 +266,7 @@ struct FoldWs { float *stat, *part; size_t per_layer, bytes; };
 FoldWs fold_carve(char* base, long T, int D, int nlayers, int train, FoldLayer* out) {
   FoldWs f;
   const size_t w1 = al((size_t)3 * D * D * 2), w2 = al((size_t)4 * D * D * 2), c1 = al((size_t)2 * 3 * D * 4), c2 = al((size_t)2 * 4 * D * 4);
-  const size_t g1 = train ? al((size_t)3 * D * D * 4) : 0, g2 = train ? al((size_t)4 * D * D * 4) : 0, vm = train ? al((size_t)7 * D * 4) : 0;
+  const size_t g1 = train ? al((size_t)3 * D * D * 4) : 0, g2 = train ? al((size_t)4 * D * D * 4) : 0, vm = train ? al((size_t)(7 * D + 2 * 2 * 8 * D) * 4) : 0;      // 2 x hmmc_fold_grad_scratch_floats
   f.per_layer = w1 + w2 + c1 + c2 + g1 + g2 + vm;
   char* p = base;
   for (int i = 0; i < nlayers; ++i) {
@@ -706,7 +706,7 @@ static int tower_bwd_impl(const void* dy, void* dx, const void* x0, const void* 
         S[n] = f.s1; W[n] = P[2]; gm[n] = (const float*)P[0]; bt[n] = (const float*)P[1]; db[n] = G[3]; dW[n] = G[2]; dg[n] = (float*)G[0];
         dbt[n] = (float*)G[1]; vm[n] = f.vm; N[n] = 3 * D; ++n;
         S[n] = f.s2; W[n] = P[8]; gm[n] = (const float*)P[6]; bt[n] = (const float*)P[7]; db[n] = G[9]; dW[n] = G[8]; dg[n] = (float*)G[6];
-        dbt[n] = (float*)G[7]; vm[n] = f.vm + 3 * D; N[n] = 4 * D; ++n;
+        dbt[n] = (float*)G[7]; vm[n] = f.vm + 3 * D + 2 * 8 * D; N[n] = 4 * D; ++n;
       }
       CK(hmmc_fold_grad_finish(S, W, gm, bt, db, dW, dg, dbt, vm, N, D, n, s));
     }

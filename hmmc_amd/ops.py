@@ -216,7 +216,7 @@ def fold_grad_finish(items):
         _chk(S, torch.float32, "S"); _chk(W, torch.float16, "W"); _chk(gm, torch.float32, "gamma"); _chk(bt, torch.float32, "beta")
         _chk(db, torch.float16, "db")
         outs.append((torch.empty_like(W), torch.empty(K, dtype=torch.float32, device=W.device), torch.empty(K, dtype=torch.float32, device=W.device)))
-        vms.append(torch.empty(W.shape[0], dtype=torch.float32, device=W.device))
+        vms.append(torch.empty(query("hmmc_fold_grad_scratch_floats", W.shape[0], K), dtype=torch.float32, device=W.device))
     P = ctypes.c_void_p * n
     pa = lambda ts: P(*[t.data_ptr() for t in ts])
     call("hmmc_fold_grad_finish", pa([i[0] for i in items]), pa([i[1] for i in items]), pa([i[2] for i in items]), pa([i[3] for i in items]),

@@ -104,7 +104,8 @@ int hmmc_gemm_f16(const void* A, const void* B, void* C, int M, int N, int K, in
  * taken against the RAW rows, S = dy~^T x in fp32 (hmmc_gemm_f16_wgrad_group's dW32), and hmmc_fold_grad_finish turns up to
  * 32 such sums into dW = gamma_k (S - rowmean(S)) + beta_k db_n (fp16), dgamma_k = sum_n W[n][k] (S - rowmean(S))[n][k] and
  * dbeta_k = sum_n W[n][k] db_n (fp32) - sum_k (x[r][k] - mean_r) = 0 makes each row's mean correction that row's own mean.
- * HOST arrays of `count` entries; db_e: the layer's fp16 bias gradient [N_e]; vmean_e: fp32 [N_e] scratch. */
+ * HOST arrays of `count` entries; db_e: the layer's fp16 bias gradient [N_e]; vmean_e: fp32 scratch of
+ * hmmc_fold_grad_scratch_floats(N_e, K) floats. */
 int hmmc_ln_fold_prep(const void* const* W, const float* const* gamma, const float* const* beta, const void* const* bias,
                       void* const* Wf, float* const* cd, const int* N, int K, int count, hmmc_stream_t stream);
 int hmmc_rowstat(const void* x, float* stat, int rows, int D, long stride, float eps, hmmc_stream_t stream);
@@ -115,6 +116,7 @@ int hmmc_gemm_f16_fold(const void* A, const void* B, void* C, int M, int N, int 
 int hmmc_layernorm_bwd_fold_rows(int rows);
 int hmmc_layernorm_bwd_fold(const void* dut, const void* x, const float* stat, const void* dres, void* dx, float* partial,
                             int want_dx_colsum, int rows, int D, long stride, hmmc_stream_t stream);
+size_t hmmc_fold_grad_scratch_floats(int N, int K);   /* floats of each vmean_e */
 int hmmc_fold_grad_finish(const float* const* S, const void* const* W, const float* const* gamma, const float* const* beta,
                           const void* const* db, void* const* dW, float* const* dgamma, float* const* dbeta, float* const* vmean,
                           const int* N, int K, int count, hmmc_stream_t stream);
