@@ -31,6 +31,7 @@ SIGNATURES = {
     "hmmc_rowstat": ("ppiilfp", "i"),
     "hmmc_rowstat_finalize": ("ppiiifp", "i"),
     "hmmc_tower_fold_bytes": ("liii", "z"),
+    "hmmc_tower_act_bytes_fold": ("liiii", "z"),
     "hmmc_tower_fwd_fused": ("pppppiiiiiiifiipzp", "i"),
     "hmmc_vit_embed_ln": ("pppppppppiiifip", "i"),
     "hmmc_gemm_f16_wgrad_group_workspace": ("ppii", "z"),

@@ -67,16 +67,17 @@ struct Acts {
   size_t bytes;
 };
 
-Acts carve(char* base, long T, int D, int nseq, int L, int H, int es, bool f32) {
+// skip_ln: a layer that runs with its LayerNorms folded keeps no normalised activations (ln1 / ln2 are null)
+Acts carve(char* base, long T, int D, int nseq, int L, int H, int es, bool f32, bool skip_ln = false) {
   Acts a;
   size_t td = al((size_t)T * D * es);
   char* p = base;
   a.x = p; p += td;
-  a.ln1 = p; p += td;
+  a.ln1 = skip_ln ? nullptr : p; p += skip_ln ? 0 : td;
   a.qkv = p; p += al((size_t)T * 3 * D * es);
   a.att = p; p += td;
   a.x1 = p; p += td;
-  a.ln2 = p; p += td;
+  a.ln2 = skip_ln ? nullptr : p; p += skip_ln ? 0 : td;
   a.h = p; p += al((size_t)T * 4 * D * es);
   a.g = p; p += al((size_t)T * 4 * D * es);
   a.m1 = (float*)p; p += al((size_t)T * 4);
@@ -123,6 +124,11 @@ inline int wgrad(bool f32, const void* dy, const void* x, void* dw, int T, int N
 
 extern "C" size_t hmmc_tower_act_bytes(long tokens, int D, int nseq, int L, int heads, int fp32) {
   return carve(nullptr, tokens, D, nseq, L, heads, fp32 ? 4 : 2, fp32 != 0).bytes;
+}
+// slab of a layer hmmc_tower_fwd_fused(keep_acts = 1) runs folded (no ln_1 / ln_2 outputs): the acts buffer of such a call is
+// nfold of these followed by (nlayers - nfold) of hmmc_tower_act_bytes(), nfold = nlayers - (last_exact ? 1 : 0)
+extern "C" size_t hmmc_tower_act_bytes_fold(long tokens, int D, int nseq, int L, int heads) {
+  return carve(nullptr, tokens, D, nseq, L, heads, 2, false, true).bytes;
 }
 
 // transient gradients of the backward: dh [T,4D], dqkv [T,3D], dln [T,D], dx1 [T,D], ping/pong dx [T,D] x2; the fp16 tower holds
@@ -313,7 +319,13 @@ extern "C" int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y,
   std::vector<FoldLayer> fl(nlayers);
   const FoldWs fw = fold_carve((char*)fold_ws, T, D, nlayers, keep_acts, fl.data());
   if (fold_bytes < fw.bytes) return HMMC_ERR_WORKSPACE;
-  const size_t slab = hmmc_tower_act_bytes(T, D, nseq, L, heads, 0);
+  const size_t slab = hmmc_tower_act_bytes(T, D, nseq, L, heads, 0), slab_f = hmmc_tower_act_bytes_fold(T, D, nseq, L, heads);
+  // layer i's saved activations (training): folded layers first, in the compact slab
+  auto acts_of = [&](int i) {
+    if (!keep_acts) return carve((char*)acts, T, D, nseq, L, heads, 2, false);
+    const size_t off = i < nfold ? (size_t)i * slab_f : (size_t)nfold * slab_f + (size_t)(i - nfold) * slab;
+    return carve((char*)acts + off, T, D, nseq, L, heads, 2, false, i < nfold);
+  };
   // folded weights and column terms of every folded layer (16 layers = 32 matrices per launch)
   for (int l0 = 0; l0 < nfold; l0 += 16) {
     const void* W[32]; const float* gm[32]; const float* bt[32]; const void* bs[32]; void* Wf[32]; float* cd[32]; int N[32];
@@ -329,11 +341,10 @@ extern "C" int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y,
   const void* cur = x;
   for (int i = 0; i < nlayers; ++i) {
     const void* const* P = params + (size_t)i * 12;
-    Acts a = carve((char*)acts + (keep_acts ? (size_t)i * slab : 0), T, D, nseq, L, heads, 2, false);
+    Acts a = acts_of(i);
     const void* xin = cur;
     void* out = y;
-    if (i + 1 < nlayers) out = keep_acts ? carve((char*)acts + (size_t)(i + 1) * slab, T, D, nseq, L, heads, 2, false).x
-                                         : (void*)(((i & 1) == 0) ? a.x : a.h);
+    if (i + 1 < nlayers) out = keep_acts ? (void*)acts_of(i + 1).x : (void*)(((i & 1) == 0) ? a.x : a.h);
     const bool lead = lead_only && i + 1 == nlayers;
     const int ldl = L * D;
     if (i >= nfold) {
@@ -387,7 +398,7 @@ extern "C" int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y,
     CK(hmmc_gemm_f16_fold(a.g, P[10], out, (int)T, D, 4 * D, 4 * D, 4 * D, D, 1, P[11], a.x1, nullptr, nullptr,
                           EPI_BIAS | EPI_RESID | (more ? EPI_ROWSTAT : 0), nullptr, nullptr, more ? fw.part : nullptr, nullptr, 0, s));
     if (more) {
-      float* const next = keep_acts ? carve((char*)acts + (size_t)(i + 1) * slab, T, D, nseq, L, heads, 2, false).m1 : fw.stat;
+      float* const next = keep_acts ? acts_of(i + 1).m1 : fw.stat;
       CK(hmmc_rowstat_finalize(fw.part, next, nparts, (int)T, D, eps, s));
     }
     cur = out;
@@ -550,7 +561,14 @@ static int tower_bwd_impl(const void* dy, void* dx, const void* x0, const void* 
   for (int i = nlayers - 1; i >= 0; --i) {
     const void* const* P = params + (size_t)i * 12;
     void* const* G = grads + (size_t)i * 12;
-    Acts a = carve((char*)acts + (size_t)i * slab, T, D, nseq, L, heads, es, f32);
+    Acts a;
+    if (fb) {
+      const size_t slab_f = hmmc_tower_act_bytes_fold(T, D, nseq, L, heads);
+      const size_t off = i < fb->nfold ? (size_t)i * slab_f : (size_t)fb->nfold * slab_f + (size_t)(i - fb->nfold) * slab;
+      a = carve((char*)acts + off, T, D, nseq, L, heads, es, f32, i < fb->nfold);
+    } else {
+      a = carve((char*)acts + (size_t)i * slab, T, D, nseq, L, heads, es, f32);
+    }
     const void* xin = i == 0 ? x0 : (const void*)a.x;
     void* g_out = i == 0 ? dx : ping[i & 1];
     char* const sl = part_base + (size_t)i * slot.bytes;           // this layer's slot of partial matrices (fp16 tower)

@@ -201,7 +201,12 @@ def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep, lead_only
     T, D = x.shape
     nl = len(params) // PER_LAYER
     slab = query("hmmc_tower_act_bytes", T, D, nseq, L, heads, int(fp32))
-    acts = torch.empty(slab * (nl if keep else 1), dtype=torch.uint8, device=x.device)
+    if fold and keep and not fp32:                 # folded layers keep no normalised activations: a smaller slab each
+        nfold = nl - int(fold == "last_exact")
+        acts = torch.empty(query("hmmc_tower_act_bytes_fold", T, D, nseq, L, heads) * nfold + slab * (nl - nfold), dtype=torch.uint8,
+                           device=x.device)
+    else:
+        acts = torch.empty(slab * (nl if keep else 1), dtype=torch.uint8, device=x.device)
     if fold and not keep and not fp32 and (T + 256) * 4 * D * 2 < (1 << 31) - (1 << 24):
         fwb = query("hmmc_tower_fold_bytes", T, D, nl, 0)
         fws = ops.workspace(fwb, x.device, "tower_fold")

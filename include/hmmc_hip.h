@@ -344,11 +344,14 @@ int hmmc_tower_fwd(const void* x, void* y, const void* const* params, void* acts
 /* hmmc_tower_fwd for an fp16 tower with ln_1 / ln_2 folded into in_proj / c_fc (hmmc_gemm_f16_fold above): no LayerNorm pass over
  * the residual stream, the row statistics come out of the out_proj / c_proj epilogues.  keep_acts = 0 (eval, the momentum
  * encoders of modules/modeling.py:347-357): acts is ONE slab of hmmc_tower_act_bytes(), fold_ws hmmc_tower_fold_bytes(.., 0).
- * keep_acts = 1 (training): acts holds nlayers slabs, fold_ws hmmc_tower_fold_bytes(.., 1) and BOTH go to hmmc_tower_bwd_fold;
+ * keep_acts = 1 (training): acts as hmmc_tower_act_bytes_fold describes, fold_ws hmmc_tower_fold_bytes(.., 1), BOTH go to hmmc_tower_bwd_fold;
  * needs L <= 64, D % 256 == 0, >= 2048 tokens, and last_exact when lead_only.  last_exact = 1: the LAST layer runs on the
  * unfolded kernels.  x_stat (may be NULL): the row pairs of x as hmmc_rowstat / hmmc_vit_embed_ln give them.  Returns
  * HMMC_ERR_UNSUPPORTED for operands of 2 GiB and more or shapes outside the above (use hmmc_tower_fwd). */
 size_t hmmc_tower_fold_bytes(long tokens, int D, int nlayers, int train);
+/* slab of a layer that runs folded with keep_acts = 1 (no ln_1 / ln_2 outputs are kept): acts of such a call = nfold of these
+ * followed by (nlayers - nfold) slabs of hmmc_tower_act_bytes(), nfold = nlayers - (last_exact ? 1 : 0) */
+size_t hmmc_tower_act_bytes_fold(long tokens, int D, int nseq, int L, int heads);
 int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y, const void* const* params, void* acts, int keep_acts, int nseq,
                          int L, int heads, int D, int nlayers, int causal, float eps, int lead_only, int last_exact, void* fold_ws,
                          size_t fold_bytes, hmmc_stream_t stream);
