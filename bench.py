@@ -558,6 +558,14 @@ def main():
     import hmmc_amd.functional as _fn
     import hmmc_amd.modeling as _md
     ov = (_md._OVERLAP_TOWERS, _fn._WGRAD_STREAM)
+    # The text tower's AccumulateGrad nodes were created under the side stream; as long as the last graph (`loss`) lives they are
+    # reused, and torch warns ("AccumulateGrad node's stream does not match") when the single-stream steps below produce their
+    # gradients on the main stream.  Dropping the graph first lets the next forward create them under the stream it runs on.
+    # (scratch/accgrad_warning.py: the steady-state loop never warns; a direct text-encoder call on the main stream before the
+    # overlapped forward - what several tests do - does, once.)
+    del loss
+    import gc
+    gc.collect()
     _md._OVERLAP_TOWERS, _fn._WGRAD_STREAM = False, False
     step(args.warmup + args.steps)                       # settle the single-stream workspaces
     torch.cuda.synchronize()

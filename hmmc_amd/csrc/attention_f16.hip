@@ -343,13 +343,12 @@ extern "C" int hmmc_attention_f16_bwd(const void* qkv, const void* out, const fl
   return attention_bwd(qkv, out, lse, dout, dqkv, dbias_partial, nullptr, nseq, L, H, causal, stream);
 }
 
-// the same with every row of dqkv multiplied by rowstat[token][0] on its way out (sequences of at most 64 tokens): the
+// the same with every row of dqkv multiplied by rowstat[token][0] on its way out: the
 // gradient a folded ln_1 -> in_proj consumes (ln_fold.hip); dbias_partial stays the column sums of the unscaled gradient
 extern "C" int hmmc_attention_f16_bwd_scaled(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
                                              float* dbias_partial, const float* rowstat, int nseq, int L, int H, int causal,
                                              hipStream_t stream) {
   if (!rowstat) return HMMC_ERR_ARG;
-  if (L > 64) return HMMC_ERR_UNSUPPORTED;
   return attention_bwd(qkv, out, lse, dout, dqkv, dbias_partial, rowstat, nseq, L, H, causal, stream);
 }
 
@@ -360,7 +359,7 @@ static int attention_bwd(const void* qkv, const void* out, const float* lse, con
   if (L > 64) {
     AttnArgs pl{};
     pl.qkv = (const half_t*)qkv; pl.out = (half_t*)out; pl.lse = (float*)lse; pl.dout = (const half_t*)dout;
-    pl.dqkv = (half_t*)dqkv; pl.dbias = dbias_partial; pl.nseq = nseq; pl.L = L; pl.H = H; pl.causal = causal;
+    pl.dqkv = (half_t*)dqkv; pl.dbias = dbias_partial; pl.rowstat = rowstat; pl.nseq = nseq; pl.L = L; pl.H = H; pl.causal = causal;
     return hmmc_attention_long_bwd(pl, stream);
   }
   AttnArgs p{};

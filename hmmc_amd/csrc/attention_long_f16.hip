@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
   float* lse_s = reinterpret_cast<float*>(dtile + ROWS * DH + NW * 16 * LDS_STRIDE);
   float* del_s = lse_s + ROWS;
   float* red = del_s + ROWS;                     // [3][NW][64]: every wave's column sums of its dQ / dK / dV tiles
+  float* rsc_s = red + 3 * NW * 64;              // [ROWS]: the row factors of the head's tokens (p.rowstat; 1 without)
   const bool want_dbias = p.dbias != nullptr;
   const int nt = (L + 15) / 16;                  // 16-row tiles that hold a real token
   constexpr float C1 = 0.125f * LOG2E;
@@ -244,10 +245,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
     // a query tile's Q / dO / O rows, lane-ordered (row (lane >> 3) + 8 t, bytes 16 (lane & 7) .. +15), and its log-sum-exp
     u4v rq[2], rd[2], ro[2];
     float rl;
-    // INVARIANT (the s_waitcnt vmcnt(6) below counts on it): load_tile is exactly TILE_LOADS = 7 vector-memory loads - six 16-byte
-    // loads (16-byte aligned: one instruction each, nothing to merge or split) and one dword - every result is consumed, and the
-    // "memory" clobber of the wait keeps all seven in front of it.  Changing the number of loads here means changing that count.
-    constexpr int TILE_LOADS = 7;
+    // INVARIANT (the s_waitcnt vmcnt(7) below counts on it): load_tile is exactly TILE_LOADS = 8 vector-memory loads - six 16-byte
+    // loads (16-byte aligned: one instruction each, nothing to merge or split) and two dwords - every result is consumed, and the
+    // "memory" clobber of the wait keeps all eight in front of it.  Changing the number of loads here means changing that count.
+    constexpr int TILE_LOADS = 8;
+    const float* const rs_g = p.rowstat ? p.rowstat + 2 * (long)n * L : lse_g;    // (lse_g: a valid address; the value is not used)
+    float rsv;
     auto load_tile = [&](int qt) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -257,11 +260,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
         ro[t] = *reinterpret_cast<const u4v*>(o + row * D + 8 * (lane & 7));
       }
       rl = lse_g[min(qt * 16 + c, L - 1)];
+      rsv = rs_g[p.rowstat ? 2 * min(qt * 16 + c, L - 1) : 0];
     };
     load_tile(min(wid, nt - 1));                 // requested BEFORE the DMAs below: the in-order vmcnt then does not make the
                                                  // first tile wait for 56 KiB of images
-    static_assert(TILE_LOADS == 7, "the wait below leaves TILE_LOADS - 1 loads in flight");
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but 6 of those 7 loads: the K / V images of this head (older) have landed
+    static_assert(TILE_LOADS == 8, "the wait below leaves TILE_LOADS - 1 loads in flight");
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");   // all but 7 of those 8 loads: the K / V images of this head (older) have landed
     __syncthreads();
     {                                            // this head's Q and dO images: needed in phase 2, in flight under phase 1
       dma_image<ROWS, NW>(rsrc_qkv(n), qtile, (unsigned)(h * DH * 2), ldb, wid, lane);
@@ -299,7 +303,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
         if ((lane & 7) == 0) del_s[row] = dlv[t];
       }
       const float lq = qi < L ? LOG2E * rl : INFINITY;          // +inf past L: those queries' probabilities vanish
-      if (g == 0) lse_s[qi] = lq;
+      const float sq = p.rowstat ? rsv : 1.0f;                  // row factor of token qi (hmmc_attention_f16_bwd_scaled)
+      if (g == 0) { lse_s[qi] = lq; rsc_s[qi] = sq; }
       // rows -> staging tile -> fragments (rows past L as zeros), Q then dO through the same tile (a wave's LDS operations are in order)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
         acc[dt] *= 0.125f;
       }
       if (qt + NW < nt) load_tile(qt + NW);          // the wave's second tile: requested under the dQ stores of the first
-      store_rows(dq, ld, acc, qt * 16, L, scr, lane);
+      store_rows(dq, ld, acc, qt * 16, L, scr, lane, sq);
       if (want_dbias) add_rounded(csum, acc);        // queries past L are exact zeros (their dS is)
     }
     if (want_dbias) store_colsum(red + wid * 64, csum, lane);
@@ -443,8 +448,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) ak[dt] *= 0.125f;
-      store_rows(dv, ld, av, kt * 16, L, scr, lane);
-      store_rows(dk, ld, ak, kt * 16, L, scr, lane);
+      const float sk = kt * 16 + c < nt * 16 ? rsc_s[kt * 16 + c] : 1.0f;      // phase 1 wrote the factors of every real tile
+      store_rows(dv, ld, av, kt * 16, L, scr, lane, sk);
+      store_rows(dk, ld, ak, kt * 16, L, scr, lane, sk);
       if (want_dbias) { add_rounded(csum, av); add_rounded(csk, ak); }   // keys past L are exact zeros (P and dS are)
     }
     // in_proj bias-gradient partials of this (sequence, head): the waves' sums in wave order (fixed: bit-stable)
@@ -504,7 +510,7 @@ int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream) {
 template <int KTL, int NW, bool CAUSAL>
 static void launch_long_bwd2(const AttnArgs& p, hipStream_t stream) {
   constexpr int LDS = 4 * 16 * KTL * DH * 2 + NW * 16 * LDS_STRIDE * 2 + 2 * 16 * KTL * 4   // K, V, Q, dO images + staging per wave + lse, delta
-                      + 3 * NW * 64 * 4;                                                 // + the waves' column sums
+                      + 3 * NW * 64 * 4 + 16 * KTL * 4;                                  // + the waves' column sums + the row factors
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool done[HMMC_MAX_DEVICES] = {false};
   hmmc_allow_lds((const void*)attn_long_bwd_kernel<KTL, NW, CAUSAL>, LDS, done);

@@ -312,9 +312,8 @@ extern "C" int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y,
   if (!x || !y || !params || !acts || !fold_ws || nseq <= 0 || L <= 0 || heads <= 0 || nlayers <= 0 || D != heads * 64) return HMMC_ERR_ARG;
   const long T = (long)nseq * L;
   if ((uint64_t)(T + 256) * 4 * D * 2 >= (1ull << 31) - (1ull << 24)) return HMMC_ERR_UNSUPPORTED;     // operands of 2 GiB: hmmc_tower_fwd
-  // training: the scaled attention backward exists for the short kernel only, the folded weight gradients for the grouped launch,
-  // and a lead-only last layer must be the unfolded one
-  if (keep_acts && (L > 64 || group_ws_bytes(T, D) == 0 || (lead_only && !last_exact))) return HMMC_ERR_UNSUPPORTED;
+  // training: the folded weight gradients exist for the grouped launch, and a lead-only last layer must be the unfolded one
+  if (keep_acts && (L > 256 || group_ws_bytes(T, D) == 0 || (lead_only && !last_exact))) return HMMC_ERR_UNSUPPORTED;
   const int nfold = nfold_of(nlayers, last_exact);
   std::vector<FoldLayer> fl(nlayers);
   const FoldWs fw = fold_carve((char*)fold_ws, T, D, nlayers, keep_acts, fl.data());
@@ -456,14 +455,14 @@ extern "C" int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const vo
 // epilogue HMMC_EPI_ROWSCALE, hmmc_attention_f16_bwd_scaled), the data gradients go through the folded weights, the
 // LayerNorm backward needs no gamma (hmmc_layernorm_bwd_fold), the in_proj / c_fc weight gradients are taken against the raw
 // residual stream into fp32 and finished - together with dgamma / dbeta of ln_1 / ln_2 - by ONE hmmc_fold_grad_finish at the
-// end (ln_fold.hip has the algebra).  Needs the grouped weight-gradient path (D % 256 == 0, >= 2048 tokens) and L <= 64.
+// end (ln_fold.hip has the algebra).  Needs the grouped weight-gradient path (D % 256 == 0, >= 2048 tokens).
 extern "C" int hmmc_tower_bwd_fold(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads,
                                    const void* acts, void* fold_ws, size_t fold_bytes, void* scratch, int nseq, int L, int heads, int D,
                                    int nlayers, int causal, int lead_only, int last_exact, void* workspace, size_t ws_bytes,
                                    hipStream_t wgrad_stream, hipStream_t s) {
   if (!fold_ws || nseq <= 0 || L <= 0 || nlayers <= 0) return HMMC_ERR_ARG;
   const long T = (long)nseq * L;
-  if (L > 64 || group_ws_bytes(T, D) == 0 || (lead_only && !last_exact)) return HMMC_ERR_UNSUPPORTED;
+  if (L > 256 || group_ws_bytes(T, D) == 0 || (lead_only && !last_exact)) return HMMC_ERR_UNSUPPORTED;
   std::vector<FoldLayer> fl(nlayers);
   const FoldWs fw = fold_carve((char*)fold_ws, T, D, nlayers, 1, fl.data());
   if (fold_bytes < fw.bytes) return HMMC_ERR_WORKSPACE;

@@ -195,7 +195,7 @@ int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, int nseq, int
  * the in-projection bias gradient; the caller finishes with hmmc_colsum over the nseq rows instead of re-reading dqkv. */
 int hmmc_attention_f16_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
                            float* dbias_partial, int nseq, int L, int H, int causal, hmmc_stream_t stream);
-/* The same (L <= 64) with row r of dqkv multiplied by rowstat[r][0] on its way out - the rstd of a folded ln_1, see
+/* The same with row r of dqkv multiplied by rowstat[r][0] on its way out - the rstd of a folded ln_1, see
  * hmmc_gemm_f16_fold; dbias_partial stays the column sums of the unscaled gradient. */
 int hmmc_attention_f16_bwd_scaled(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
                                   float* dbias_partial, const float* rowstat, int nseq, int L, int H, int causal,
@@ -345,7 +345,7 @@ int hmmc_tower_fwd(const void* x, void* y, const void* const* params, void* acts
  * the residual stream, the row statistics come out of the out_proj / c_proj epilogues.  keep_acts = 0 (eval, the momentum
  * encoders of modules/modeling.py:347-357): acts is ONE slab of hmmc_tower_act_bytes(), fold_ws hmmc_tower_fold_bytes(.., 0).
  * keep_acts = 1 (training): acts as hmmc_tower_act_bytes_fold describes, fold_ws hmmc_tower_fold_bytes(.., 1), BOTH go to hmmc_tower_bwd_fold;
- * needs L <= 64, D % 256 == 0, >= 2048 tokens, and last_exact when lead_only.  last_exact = 1: the LAST layer runs on the
+ * needs D % 256 == 0, >= 2048 tokens, and last_exact when lead_only.  last_exact = 1: the LAST layer runs on the
  * unfolded kernels.  x_stat (may be NULL): the row pairs of x as hmmc_rowstat / hmmc_vit_embed_ln give them.  Returns
  * HMMC_ERR_UNSUPPORTED for operands of 2 GiB and more or shapes outside the above (use hmmc_tower_fwd). */
 size_t hmmc_tower_fold_bytes(long tokens, int D, int nlayers, int train);

@@ -223,9 +223,9 @@ def test_layernorm_backward_folded(rows, D):
     assert relerr(dx2, xd.grad) < 1e-3
 
 
-def test_scaled_attention_backward():
+@pytest.mark.parametrize("nseq,L,H", [(96, 50, 12), (24, 197, 12), (40, 77, 8)])
+def test_scaled_attention_backward(nseq, L, H):
     g = torch.Generator(device=DEV).manual_seed(5)
-    nseq, L, H = 96, 50, 12
     qkv = torch.randn(nseq * L, 3 * 64 * H, device=DEV, generator=g).half()
     out, lse = ops.attention_f16_fwd(qkv, nseq, L, H, False)
     dout = (torch.randn(nseq * L, 64 * H, device=DEV, generator=g) * 0.1).half()
@@ -293,7 +293,8 @@ def _tower_and_reference(width, heads, L, nseq, layers, causal):
     return tw, x0, wsel, fp32_run
 
 
-@pytest.mark.parametrize("width,heads,L,nseq,layers,causal", [(256, 4, 10, 210, 3, False), (768, 12, 50, 64, 3, False), (512, 8, 32, 96, 2, True)])
+@pytest.mark.parametrize("width,heads,L,nseq,layers,causal", [(256, 4, 10, 210, 3, False), (768, 12, 50, 64, 3, False), (512, 8, 32, 96, 2, True),
+                                                              (768, 12, 197, 16, 2, False)])
 def test_folded_training_tower_against_fp32_autograd(width, heads, L, nseq, layers, causal, monkeypatch):
     """hmmc_tower_fwd_fused(keep_acts) + hmmc_tower_bwd_fold: output, input gradient and EVERY parameter gradient against fp64
     autograd through the same blocks - as close as the unfolded kernels are (x 1.5), tensor by tensor."""
