@@ -442,6 +442,9 @@ def main():
                          "giving it with --gpus 1 measures what the reservation costs")
     ap.add_argument("--roofline-steps", type=int, default=3,
                     help="extra single-stream steps after the timed region over which the GEMM launches are timed with HIP events")
+    ap.add_argument("--no-hbm-roofline", action="store_true",
+                    help="skip the roofline_hbm leg (its stand-alone LayerNorm / attention / optimizer launches would otherwise sit in a "
+                         "kernel trace of this command)")
     ap.add_argument("--vit-forward-iters", type=int, default=5, help="timed frame-encoder forward passes for the vit_forward record (0: skip)")
     args = ap.parse_args()
     if args.batch is None:
@@ -564,19 +567,21 @@ def main():
     # (scratch/accgrad_warning.py: the steady-state loop never warns; a direct text-encoder call on the main stream before the
     # overlapped forward - what several tests do - does, once.)
     del loss
-    import gc
-    gc.collect()
-    _md._OVERLAP_TOWERS, _fn._WGRAD_STREAM = False, False
-    step(args.warmup + args.steps)                       # settle the single-stream workspaces
-    torch.cuda.synchronize()
-    ops.gemm_profile_start()
-    t1 = time.perf_counter()
-    for i in range(args.roofline_steps):
-        step(args.warmup + args.steps + 1 + i)
-    torch.cuda.synchronize()
-    dt_single = time.perf_counter() - t1
-    prof = ops.gemm_profile_stop()
-    _md._OVERLAP_TOWERS, _fn._WGRAD_STREAM = ov
+    prof, dt_single = {}, 0.0
+    if args.roofline_steps > 0:                          # (0: nothing after the timed region - kernel traces of the plain loop)
+        import gc
+        gc.collect()
+        _md._OVERLAP_TOWERS, _fn._WGRAD_STREAM = False, False
+        step(args.warmup + args.steps)                   # settle the single-stream workspaces
+        torch.cuda.synchronize()
+        ops.gemm_profile_start()
+        t1 = time.perf_counter()
+        for i in range(args.roofline_steps):
+            step(args.warmup + args.steps + 1 + i)
+        torch.cuda.synchronize()
+        dt_single = time.perf_counter() - t1
+        prof = ops.gemm_profile_stop()
+        _md._OVERLAP_TOWERS, _fn._WGRAD_STREAM = ov
 
     # ViT forward alone (north_star: MFMA utilisation of the ViT forward): the frame encoder over this rank's b x F frames in
     # eval mode, timed with events on the current stream; FLOPs in the reference's formulation (all-token final projection)
@@ -610,7 +615,7 @@ def main():
                                "points follow the reference's. frac_of_mfma_peak counts the FLOPs this path executes (last block's "
                                "per-token half and the projection on the class token only), the reference-formulation figure "
                                "counts the reference's"}
-    hbm = hbm_rooflines(dev, b, args.frames, dims, params, optimizer, model, pretrain) if world == 1 else None
+    hbm = hbm_rooflines(dev, b, args.frames, dims, params, optimizer, model, pretrain) if world == 1 and not args.no_hbm_roofline else None
     comm = comm_leg(args, dev, model, net, params, step, b, args.frames) if world > 1 else None
 
     if rank == 0:
@@ -628,7 +633,7 @@ def main():
                 "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),
                 "measured_over": f"{args.roofline_steps} single-stream steps after the timed region "
                                  f"({dt_single / max(args.roofline_steps, 1) * 1e3:.2f} ms/step without the stream overlap)",
-                "gemm_share_of_step": round(secs / dt_single, 4),
+                "gemm_share_of_step": round(secs / dt_single, 4) if dt_single > 0 else None,
                 "algorithmic_bytes_per_launch": round(sum(p.get("bytes", 0) for p in prof.values()) / max(launches, 1)) or None,
                 "by_layout": {k: {"tflops": round(p["flops"] / p["seconds"] / 1e12, 1), "launches": p["launches"],
                                   "avg_us": round(p["seconds"] / p["launches"] * 1e6, 2)} for k, p in prof.items()}}
