@@ -329,7 +329,7 @@ def hbm_rooflines(dev, b, frames, dims, params, optimizer, model, pretrain):
         _time_us(lambda: ops.layernorm_bwd(dy, x, gm, mean, rstd, dres=dres, want_colsum=True)))
     st = ops.rowstat(x)
     add(f"ln_bwd_fold [{T}, {D}] fp16 (backward of a folded LayerNorm: + residual gradient, dx column sums)", 4 * T * D * 2,
-        _time_us(lambda: ops.layernorm_bwd_fold(dy, x, st, dres=dres, want_colsum=True)))
+        _time_us(lambda: ops.layernorm_bwd_fold(dy, x, st, dres=dres, want_colsum=True, reduce=False)))
     add(f"attn_fwd {nseq} x {L} tokens x {H} heads", 4 * T * D * 2, _time_us(lambda: ops.attention_f16_fwd(qkv, nseq, L, H, False)))
     add(f"attn_bwd {nseq} x {L} tokens x {H} heads (+ in_proj bias partials)", 7 * T * D * 2,
         _time_us(lambda: ops.attention_f16_bwd(qkv, att, lse, dy, nseq, L, H, False, want_dbias=True)))

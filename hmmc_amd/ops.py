@@ -196,14 +196,14 @@ def gemm_f16_rowscaled_dgrad(dy, w, aux, rowstat):
     return c, part
 
 
-def layernorm_bwd_fold(dut, x, stat, dres=None, want_colsum=False):
+def layernorm_bwd_fold(dut, x, stat, dres=None, want_colsum=False, reduce=True):
     """dx = du~ - mean(du~) - u mean(du~ o u) (+ dres), u = stat[:, 0] x + stat[:, 1] (include/hmmc_hip.h) [, column sums of dx]"""
     _chk(dut, torch.float16, "dut"); _chk(x, torch.float16, "x"); _chk(stat, torch.float32, "stat")
     rows, D = x.shape
     dx = torch.empty_like(x)
     part = torch.empty((query("hmmc_layernorm_bwd_fold_rows", rows), D), dtype=torch.float32, device=x.device) if want_colsum else None
     call("hmmc_layernorm_bwd_fold", ptr(dut), ptr(x), ptr(stat), ptr(dres), ptr(dx), ptr(part), int(want_colsum), rows, D, D)
-    return (dx, part.sum(0)) if want_colsum else dx
+    return (dx, part.sum(0) if reduce else part) if want_colsum else dx
 
 
 def fold_grad_finish(items):
