@@ -96,7 +96,7 @@ def _patches_of(video4d, p, dtype, frame_index):
 
 class VitEmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, video4d, conv_w, cls, pos, ln_w, ln_b, frame_index=None):
+    def forward(ctx, video4d, conv_w, cls, pos, ln_w, ln_b, frame_index=None, want_stat=False):
         n = video4d.shape[0] if frame_index is None else frame_index.numel()
         D, _, p, _ = conv_w.shape
         L = pos.shape[0]
@@ -105,30 +105,38 @@ class VitEmbedFn(torch.autograd.Function):
         # (the loader's frame sampling)
         patches = _patches_of(video4d, p, conv_w.dtype, frame_index)
         x0 = _linear(patches, conv_w.view(D, -1))
+        stat = None
         if x0.dtype == torch.float16:                 # class / positional embedding and ln_pre in one pass (bit-identical)
-            x, mean, rstd, _ = ops.vit_embed_ln_(x0, cls, pos, ln_w, ln_b, L)
+            x, mean, rstd, stat = ops.vit_embed_ln_(x0, cls, pos, ln_w, ln_b, L, want_stat=want_stat)
         else:
             ops.vit_embed_(x0, cls, pos, L)
             x, mean, rstd = ops.layernorm_fwd(x0, ln_w, ln_b, 1e-5)
         ctx.save_for_backward(patches, x0, mean, rstd, ln_w, conv_w)
         ctx.dims = (n, L, D, p)
-        return x
+        if stat is None:
+            return x
+        ctx.mark_non_differentiable(stat)             # the row pairs of x for a folded tower (a by-product, no gradient)
+        return x, stat
 
     @staticmethod
-    def backward(ctx, dx):
+    def backward(ctx, dx, _dstat=None):
         patches, x0, mean, rstd, ln_w, conv_w = ctx.saved_tensors
         n, L, D, p = ctx.dims
         dx0, dlw, dlb = ops.layernorm_bwd(dx.contiguous(), x0, ln_w, mean, rstd)
         dconv = _wgrad(dx0, patches).view(conv_w.shape)
         dpos = ops.colsum(dx0.view(n, L * D), out_dtype=torch.float32, round_f16=dx0.dtype == torch.float16).view(L, D)
-        return None, dconv, dpos[0].clone(), dpos, dlw, dlb, None
+        return None, dconv, dpos[0].clone(), dpos, dlw, dlb, None, None
 
 
 def vit_embed(video4d, conv_w, cls, pos, ln_w, ln_b, frame_index=None):
     """VitEmbedFn.apply -> (x, row statistics of x or None).  Passes that record no graph in fp16 skip the autograd node, do
     not write the embedded rows back, and get the row pairs the folded tower forward needs from the same kernel."""
-    if (torch.is_grad_enabled() and any(t.requires_grad for t in (conv_w, cls, pos, ln_w, ln_b))) or conv_w.dtype != torch.float16:
+    if conv_w.dtype != torch.float16:
         return VitEmbedFn.apply(video4d, conv_w, cls, pos, ln_w, ln_b, frame_index), None
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (conv_w, cls, pos, ln_w, ln_b)):
+        if _FOLD_LN_TRAIN in ("0", "", "off", False):
+            return VitEmbedFn.apply(video4d, conv_w, cls, pos, ln_w, ln_b, frame_index), None
+        return VitEmbedFn.apply(video4d, conv_w, cls, pos, ln_w, ln_b, frame_index, True)      # (x, row pairs of x)
     D, _, p, _ = conv_w.shape
     L = pos.shape[0]
     patches = _patches_of(video4d, p, conv_w.dtype, frame_index)
@@ -260,7 +268,7 @@ class ClipTransformerFn(torch.autograd.Function):
     LayerNorm statistics); the per-layer activations live in a single slab laid out by the library."""
 
     @staticmethod
-    def forward(ctx, x, nseq, L, heads, causal, lead_only, fold, *params):
+    def forward(ctx, x, nseq, L, heads, causal, lead_only, fold, x_stat, *params):
         keep = any(ctx.needs_input_grad)       # no_grad passes never get here: clip_transformer() below
         x = x.contiguous()
         for prm in params:
@@ -271,7 +279,8 @@ class ClipTransformerFn(torch.autograd.Function):
             raise RuntimeError(f"expected the activations ({x.dtype}) and the tower weights to have the same dtype: after "
                                "model.float() set text_encoder.dtype = torch.float32 as well, as with the reference")
         lead_only = bool(lead_only and not fp32)        # the class-token pruning exists for the fp16 tower only
-        y, acts = _tower_forward(x, params, nseq, L, heads, causal, 1e-5, fp32, keep, lead_only, fold=fold if keep else False)
+        y, acts = _tower_forward(x, params, nseq, L, heads, causal, 1e-5, fp32, keep, lead_only, fold=fold if keep else False,
+                                 x_stat=x_stat if (keep and fold) else None)
         ctx.acts, ctx.x0, ctx.params = acts, (x if keep else None), params
         ctx.cfg = (nseq, L, heads, causal, lead_only, fp32)
         return y
@@ -281,7 +290,7 @@ class ClipTransformerFn(torch.autograd.Function):
         nseq, L, heads, causal, lead_only, fp32 = ctx.cfg
         dx, grads = _tower_backward(dy.contiguous(), ctx.x0, ctx.params, ctx.acts, nseq, L, heads, causal, fp32, lead_only)
         ctx.acts = ctx.x0 = None
-        return (dx, None, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, None, None, *grads)
 
 
 def clip_transformer(x, nseq, L, heads, causal, lead_only, *params, x_stat=None, fold=False, fold_train=False):
@@ -289,7 +298,7 @@ def clip_transformer(x, nseq, L, heads, causal, lead_only, *params, x_stat=None,
     modules/modeling.py:347-357) go straight to the forward-only runtime: `ctx.needs_input_grad` reports the inputs'
     requires_grad whatever the grad mode, so until round 4 those passes kept - and wrote - every layer's activations."""
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-        return ClipTransformerFn.apply(x, nseq, L, heads, causal, lead_only, fold_train, *params)
+        return ClipTransformerFn.apply(x, nseq, L, heads, causal, lead_only, fold_train, x_stat, *params)
     x = x.contiguous()
     fp32 = x.dtype == torch.float32
     if any(prm.dtype != (x.dtype if prm.dim() == 2 else prm.dtype) for prm in params):
