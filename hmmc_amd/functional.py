@@ -190,7 +190,9 @@ _FOLD_LN_TRAIN = os.environ.get("HMMC_FOLD_LN_TRAIN", "vit")
 def fold_train_enabled(tower_default, T, D, L):
     if _FOLD_LN_TRAIN in ("0", "", "off", False) or not (_FOLD_LN_TRAIN in ("all", "1", True) or tower_default):
         return False
-    return L <= 256 and D % 256 == 0 and T >= 2048 and (T + 256) * 4 * D * 2 < (1 << 31) - (1 << 24)
+    # the shapes hmmc_tower_fwd_fused(keep_acts = 1) takes: the grouped weight-gradient launch must exist for them
+    return (L <= 256 and D % 256 == 0 and T >= 2048 and (T + 256) * 4 * D * 2 < (1 << 31) - (1 << 24)
+            and not os.environ.get("HMMC_NO_WGRAD_GROUP"))
 
 
 def fold_enabled(tower_default):
