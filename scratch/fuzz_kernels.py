@@ -66,6 +66,52 @@ for case in range(ncases):
 torch.cuda.synchronize()
 print("gemm done, mismatches", bad, flush=True)
 
+# ---- LayerNorm-fold epilogues (round 4): LNFOLD [+ QuickGELU], ROWSTAT, ROWSCALE against fp64 on random (ragged) shapes
+for case in range(ncases):
+    M = rng.choice([8, 64, 130, 256, 300, 1000, 2048, 4104, 5000]); M -= M % 8
+    K = rng.choice([64, 128, 192, 512, 768])
+    kind = rng.choice(["fold", "foldg", "stat", "scale"])
+    N = rng.choice([64, 128, 192, 512, 768, 1536, 2304]) if kind != "fold" and kind != "foldg" else rng.choice([64, 128, 200, 512, 768, 1536])
+    N -= N % 8
+    try:
+        g = torch.Generator(device=DEV).manual_seed(case)
+        x = (torch.randn(M, K, device=DEV, generator=g) * 1.2 + 0.3).half()
+        W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).half()
+        b = (0.1 * torch.randn(N, device=DEV, generator=g)).half()
+        if kind in ("fold", "foldg"):
+            gm = 1.0 + 0.2 * torch.randn(K, device=DEV, generator=g); bt = 0.1 * torch.randn(K, device=DEV, generator=g)
+            (Wf, cd), = ops.ln_fold_prep([(W, gm, bt, b)])
+            st = ops.rowstat(x)
+            y = ops.gemm_f16_fold(x, Wf, rowstat=st, colterms=cd, epilogue=ops.EPI_QGELU if kind == "foldg" else 0)
+            xd = x.double(); mean = xd.mean(1, keepdim=True); rstd = torch.rsqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-5)
+            ex = rstd * (xd @ Wf.double().t()) - rstd * mean * Wf.double().sum(1)[None] + (W.double() * bt.double()[None]).sum(1)[None] + b.double()[None]
+            if kind == "foldg": ex = ex * torch.sigmoid(1.702 * ex)
+            err = (y.double() - ex).abs()
+            report(bool((err <= 2.5e-3 * ex.abs() + 2e-3).all()), (kind, M, N, K, float(err.max())))
+        elif kind == "stat":
+            r = (torch.randn(M, N, device=DEV, generator=g) + 0.5).half()
+            y, part = ops.gemm_f16_fold(x, W, bias=b, resid=r, want_stat=True)
+            y0 = ops.gemm_f16(x, W, M, N, K, bias=b, resid=r)
+            yb = y.float().view(M, N // 64, 64)
+            ok = torch.equal(y, y0) and torch.allclose(part[:, :, 0].t(), yb.sum(2), rtol=1e-5, atol=1e-3) and \
+                torch.allclose(part[:, :, 1].t(), (yb * yb).sum(2), rtol=1e-5, atol=1e-3)
+            report(ok, (kind, M, N, K))
+        else:
+            dy = (torch.randn(M, K, device=DEV, generator=g) * 0.1).half()             # dy [M, Np = K], w [Np, Kp = N]
+            w2 = (torch.randn(K, N, device=DEV, generator=g) * 0.05).half()
+            aux = torch.rand(M, N, device=DEV, generator=g).half()
+            st = ops.rowstat(x)
+            out, part = ops.gemm_f16_rowscaled_dgrad(dy, w2, aux, st)
+            base = (dy.double() @ w2.double()) * aux.double()
+            ref = base * st[:, :1].double()
+            err = (out.double() - ref).abs()
+            ok = bool((err <= 1.5e-3 * ref.abs() + 1e-4).all()) and torch.allclose(part.sum(0).double(), base.sum(0), rtol=3e-3, atol=3e-2)
+            report(ok, (kind, M, N, K))
+    except Exception as e:
+        print("status", (kind, M, N, K), str(e)[:80], flush=True)
+torch.cuda.synchronize()
+print("fold epilogues done, mismatches", bad, flush=True)
+
 # ---- attention
 def attn_ref(qkv, nseq, L, H, causal):
     D = H * 64
