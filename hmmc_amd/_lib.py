@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhmmc_hip.so")
+LIB_PATH = os.environ.get("HMMC_LIB") or os.path.join(_HERE, "libhmmc_hip.so")     # HMMC_LIB: a variant build (A/B runs, scratch/)
 
 _C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "z": ctypes.c_size_t}
 
