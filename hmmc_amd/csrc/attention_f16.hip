@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   // memory and reloaded behind full vmcnt waits in the middle of the MFMA stream.
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
+#if defined(HMMC_SCRATCH) && defined(HMMC_ATTN_ABL)
+    if (pass == HMMC_ATTN_ABL - 1) continue;     // timing experiments only (wrong results): 1 skips the dV pass, 2 the dK pass
+#endif
     if (pass == 0) frags_to_tile<KT>(xt, df, lane); else frags_to_tile<KT>(xt, qf, lane);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) csum[dt] = f4{0.f, 0.f, 0.f, 0.f};
