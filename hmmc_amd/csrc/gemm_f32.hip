@@ -444,6 +444,136 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
       store_tile16(p, acc[i][j], m0 + wm * 32 + i * 16 + (lane & 15), n0 + wn * 32 + j * 16 + 4 * (lane >> 4));
 }
 
+// ---- large aligned problems: (32 MI) x 64 tiles staged by LDS-DMA -----------------------------------------------------------
+// The register-staged kernel above pays, per 16-deep K-step of 16 MFMAs per wave, 16 four-byte LDS reads, the staging stores,
+// two global loads and a barrier, and sits at 55-60 % of the f32 matrix rate on the temporal transformer at 3 072 tokens and
+// the pre-training heads.  Here the operand tiles go global -> LDS without touching registers (buffer_load ... lds, 16 B per
+// lane, bounds-checked: rows past the end of an operand read as zero), a K-step is 32 deep (32 MFMAs per wave and barrier), and
+// NST - 1 steps are in flight behind a counted vmcnt.  Images (a 16-byte chunk = 4 floats):
+//   k-contiguous operand:   [rows][8 chunks]   phys chunk = logical ^ ((row >> 1) & 7)           read: one ds_read_b128 per 16 k
+//   row-contiguous operand: [32 k][16 chunks]  phys chunk = logical ^ (((k >> 2) & 3) << 2)      read: four ds_read_b32 per 16 k
+// (LDS side of a DMA is lane-linear, so the XOR is applied to the SOURCE chunk a lane fetches).  As in the kernels above the
+// MFMA's k slot kg of sub-step s is k = 16 kb + 4 kg + s for both operands.
+// Needs 16-byte aligned rows on both operands and K % 32 == 0 (the k tail of a k-contiguous row would read its neighbour).
+template <bool AKC, bool BKC, int MI>
+__device__ __forceinline__ void gemm_f32_dma_body(const G32& p, unsigned a_bytes, unsigned b_bytes, int a_fast) {
+  constexpr int BM = 32 * MI, BN = 64, BK = 32, NST = 3;
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, STAGE = A_BYTES + B_BYTES;
+  constexpr int LPT = MI + 2;                                     // LDS-DMA loads per thread and stage
+  constexpr int C_LD = 68;                                        // floats per row of the epilogue's LDS tile (272 B: 16-byte rows, +4 banks per row)
+  static_assert(BM * C_LD * 4 <= NST * STAGE, "the result tile reuses the stages");
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  // tile order: the workgroups resident together walk the SMALLER operand's tiles fastest, so the larger operand's tile is
+  // fetched once and shared (the MLM vocabulary projection: 3 MB of activations against 101 MB of weights)
+  const int tm = a_fast ? blockIdx.x % ntm : blockIdx.x / ntn, tn = a_fast ? blockIdx.x / ntm : blockIdx.x % ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int r = lane & 15, kg = lane >> 4;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)b_bytes, 0x00020000);
+  const unsigned lda = (unsigned)(AKC ? p.sam : p.sak), ldb = (unsigned)(BKC ? p.sbn : p.sbk);
+  // byte offset of the chunk this thread fetches in pass ps of an operand tile at (row0, k0 = 0); the k advance is uniform
+  auto src_off = [&](bool kc, int rows, int ps, int row0, unsigned ld) -> unsigned {
+    const int P = ps * 256 + tid;
+    if (kc) {
+      const int row = P >> 3, lc = (P & 7) ^ ((row >> 1) & 7);
+      return ((unsigned)(row0 + row) * ld + (unsigned)(lc * 4)) * 4u;
+    }
+    const int cpr = rows / 4, krow = P / cpr, pc = P % cpr;       // chunks per k-row: 8 / 16 / 32 (32 / 64 / 128 rows)
+    const int lc = pc ^ ((((krow >> 2) & 3) << 2) & (cpr - 1));
+    return ((unsigned)krow * ld + (unsigned)(row0 + lc * 4)) * 4u;
+  };
+  unsigned offa[MI], offb[2];
+#pragma unroll
+  for (int ps = 0; ps < MI; ++ps) offa[ps] = src_off(AKC, BM, ps, m0, lda);
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) offb[ps] = src_off(BKC, BN, ps, n0, ldb);
+  const unsigned stepa = AKC ? BK * 4u : BK * lda * 4u, stepb = BKC ? BK * 4u : BK * ldb * 4u;
+  const int nkt = p.K / BK;
+  auto issue = [&](int kt) {                                      // past the last step: out of range, reads as zero into a dead stage
+    char* st = dsm + (kt % NST) * STAGE;
+    const bool live = kt < nkt;
+#pragma unroll
+    for (int ps = 0; ps < MI; ++ps)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(st + ps * 4096 + wid * 1024), 16, live ? offa[ps] + (unsigned)kt * stepa : 0xfffffff0u, 0, 0, 0);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(st + A_BYTES + ps * 4096 + wid * 1024), 16, live ? offb[ps] + (unsigned)kt * stepb : 0xfffffff0u, 0, 0, 0);
+  };
+  f4 acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  // 4 sub-step values of MFMA tile `row0` of an image, k block kb
+  auto frag = [&](bool kc, const char* img, int rows, int row0, int kb) -> f4 {
+    const int row = row0 + r;
+    if (kc) return *reinterpret_cast<const f4*>(img + row * 128 + (((kb * 4 + kg) ^ ((row >> 1) & 7)) << 4));
+    f4 v;
+    const char* base = img + (16 * kb + 4 * kg) * (rows * 4) + (((row >> 2) ^ ((kg << 2) & (rows / 4 - 1))) << 4) + (row & 3) * 4;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) v[s2] = *reinterpret_cast<const float*>(base + s2 * (rows * 4));
+    return v;
+  };
+  static_assert(NST == 3, "the counted wait below leaves one stage in flight");
+  issue(0); issue(1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    // all but the newest stage have landed (this thread's part)
+    if constexpr (LPT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // ... everyone's part, and every wave's fragment reads of stage kt - 1 were consumed by its MFMAs.  The raw barrier:
+    // __syncthreads() would wait for vmcnt(0) first, i.e. for the stage that is meant to stay in flight.
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    issue(kt + 2);
+    const char* st = dsm + (kt % NST) * STAGE;
+    f4 a[2][MI], b[2][2];                                         // both k blocks requested before the first MFMA
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[kb][i] = frag(AKC, st, BM, wm * (16 * MI) + 16 * i, kb);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[kb][j] = frag(BKC, st + A_BYTES, BN, wn * 32 + 16 * j, kb);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[kb][j][s2], a[kb][i][s2], acc[i][j], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the trailing out-of-range loads, before the stages are reused
+  // Epilogue through LDS: from the MFMA layout (lane = one row, 16 bytes) to lane order (16 consecutive lanes = 256 consecutive
+  // bytes of one row), so that the stores - and the residual / auxiliary loads inside store_tile16 - are whole 256-byte row
+  // segments instead of 64-byte pieces of 16 different rows per instruction.
+  __syncthreads();
+  float* ct = reinterpret_cast<float*>(dsm);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      *reinterpret_cast<f4*>(ct + (wm * (16 * MI) + 16 * i + r) * C_LD + wn * 32 + 16 * j + 4 * kg) = acc[i][j];
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < BM / 16; ++ps) {
+    const int row = ps * 16 + (tid >> 4), col = 4 * (tid & 15);
+    store_tile16(p, *reinterpret_cast<const f4*>(ct + row * C_LD + col), m0 + row, n0 + col);
+  }
+}
+// (the body lives in a __device__ function: buffer-resource types in a __global__ template make hipcc 7.2 drop the host stub)
+template <bool AKC, bool BKC, int MI>
+__global__ __launch_bounds__(256) void gemm_f32_dma_kernel(G32 p, unsigned a_bytes, unsigned b_bytes, int a_fast) {
+  gemm_f32_dma_body<AKC, BKC, MI>(p, a_bytes, b_bytes, a_fast);
+}
+
 // packed[video * P + slot][:] = unit row: slot 0 = visual[video], 1..F = frames[video][slot - 1], slots past F zero
 // (loose_similarity normalises both sides without an epsilon, modules/modeling.py:211-213)
 __global__ __launch_bounds__(256) void eval_pack_kernel(const float* __restrict__ visual, const float* __restrict__ frames,
@@ -508,7 +638,10 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
   // rows).  Estimated times in us (fitted to measurements at 96..3072 rows of the temporal-transformer shapes) pick one.
   const double mnk = (double)M * N * K;
   const double t_small = 3.0 + mnk * ((sak == 1 && sbk == 1) ? 6.0e-8 : 3.9e-8);
-  const double t_tiled = 3.0 + (K / 16.0) * 0.40 * (0.4 + 0.6 * (double)((blocks + num_cu - 1) / num_cu));
+  // (many tiles per CU: the 64x64 kernel settles at one tile per CU per K/16 x 0.333 us - the MLM head's 72 tiles per CU)
+  const double t_tiled_few = 3.0 + (K / 16.0) * 0.40 * (0.4 + 0.6 * (double)((blocks + num_cu - 1) / num_cu));
+  const double t_tiled_many = 3.0 + (K / 16.0) * 0.333 * ((double)blocks / num_cu + 0.5);       // + half a round of imbalance
+  const double t_tiled = t_tiled_few > t_tiled_many ? t_tiled_few : t_tiled_many;
   // The wave-split-K kernel on (16 RM) x 64 tiles, for problems it covers with at most one workgroup per CU (more than one per CU
   // share the matrix pipe at ~0.7 of its rate: measured).  Matrix-rate bound: 2 RM RN K cycles per tile; the smallest RM that
   // fits the CUs gives the shortest chain.  Measured against the other two kernels on every fp32 shape of the path
@@ -516,8 +649,8 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
   // query gradient, the MLM data gradient), behind for K = 512, where the fixed ~6 us of fill and reduction decide.
   {
     static const bool off = std::getenv("HMMC_NO_F32_WAVEK") != nullptr;          // A/B runs
-#ifdef HMMC_SCRATCH      // scratch/gemm32_pick.py builds: HMMC_F32_PICK = 1 small, 2 tiled, 3.. wave-split-K RM = 2, 3, 4, 6
-    static const char* force_s = std::getenv("HMMC_F32_PICK");
+#ifdef HMMC_SCRATCH      // scratch/gemm32_pick.py builds: HMMC_F32_PICK = 1 small, 2 tiled, 3.. wave-split-K RM = 2, 3, 4, 6,
+    static const char* force_s = std::getenv("HMMC_F32_PICK");                    // 7 / 9 LDS-DMA 64x64 / 32x64
     const int force = force_s ? atoi(force_s) : 0;
 #else
     const int force = 0;
@@ -533,6 +666,41 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
       const double t = 6.0 + (double)K * rms[c] * 4 * (2.0 / 1900.0) / 0.85;
       if (t < best) { best = t; rm = rms[c]; }
       break;                                                                      // larger tiles only lengthen the chain
+    }
+    // The LDS-DMA kernel (16-byte aligned rows on both sides, whole 32-deep K-steps, 32-bit byte offsets): (32 MI) x 64 tiles,
+    // three (MI = 2) or four (MI = 1) workgroups per CU.  Measured on the temporal transformer at 3 072 tokens and the
+    // pre-training heads (scratch/gemm32_dma.py): ~8-10 us of launch, fill and drain + rounds x the tile's time at 0.78 (64x64) /
+    // 0.71 (32x64) of the matrix rate; ahead of the kernels above wherever there are several tiles per CU.
+    {
+      const uint64_t a_ext = (sak == 1 ? (uint64_t)(M - 1) * sam + K : (uint64_t)(K - 1) * sak + M) * 4;
+      const uint64_t b_ext = (sbk == 1 ? (uint64_t)(N - 1) * sbn + K : (uint64_t)(K - 1) * sbk + N) * 4;
+      const uint64_t a_reach = (sak == 1 ? (uint64_t)(M + 64) * sam : (uint64_t)K * sak + M + 64) * 4;
+      const uint64_t b_reach = (sbk == 1 ? (uint64_t)(N + 64) * sbn : (uint64_t)K * sbk + N + 64) * 4;
+      const bool dma_ok = p.avec && p.bvec && !(K & 31) && a_ext < (1ull << 31) && b_ext < (1ull << 31) && a_reach < 0xfffffff0ull &&
+                          b_reach < 0xfffffff0ull;
+      static const bool dma_off = std::getenv("HMMC_NO_F32_DMA") != nullptr;      // A/B runs
+      int mi = 0;
+      if (dma_ok && (force == 7 || force == 9)) mi = force == 7 ? 2 : 1;
+      for (int c = 1; c <= 2 && dma_ok && !dma_off && !force; ++c) {
+        const long tiles = (long)((M + 32 * c - 1) / (32 * c)) * ((N + 63) / 64);
+        const double tile_us = 32.0 * c * 64 * K * 2 / (256.0 * 2400.0);          // one tile at the CU's full f32 matrix rate
+        if (tiles < 2 * num_cu) continue;                                         // alone on its CU a workgroup hides nothing: 0.6 of the rate
+        const double t = 8.0 + (double)((tiles + num_cu - 1) / num_cu) * tile_us / (c == 2 ? 0.78 : 0.71);
+        if (t < best) { best = t; mi = c; rm = 0; }
+      }
+      if (mi) {
+        const long tiles = (long)((M + 32 * mi - 1) / (32 * mi)) * ((N + 63) / 64);
+        const int smem = 3 * (32 * mi + 64) * 32 * 4;
+        const int a_fast = (long)M < (long)N;                     // A is the smaller operand: walk its tiles fastest
+#define HMMC_DMA1(AKC, BKC, MI_) hipLaunchKernelGGL((gemm_f32_dma_kernel<AKC, BKC, MI_>), dim3((unsigned)tiles), dim3(256), smem, stream, p, \
+                                                    (unsigned)a_ext, (unsigned)b_ext, a_fast)
+#define HMMC_DMA(AKC, BKC) do { if (mi == 1) HMMC_DMA1(AKC, BKC, 1); else HMMC_DMA1(AKC, BKC, 2); } while (0)
+        const bool akc = sak == 1, bkc = sbk == 1;
+        if (akc && bkc) HMMC_DMA(true, true); else if (akc) HMMC_DMA(true, false); else if (bkc) HMMC_DMA(false, true); else HMMC_DMA(false, false);
+#undef HMMC_DMA
+#undef HMMC_DMA1
+        return hmmc_launch_status();
+      }
     }
     if (rm) {
       const long tiles = (long)((M + 16 * rm - 1) / (16 * rm)) * ((N + 63) / 64);

@@ -92,6 +92,40 @@ def test_gemm_f32_long_k_single_round_exact_integers(M, N, K):
     assert torch.equal(y, ops.gemm_f32(x, w, M, N, K, (K, 1), (1, K))), "two launches, same bits"
 
 
+@pytest.mark.parametrize("M,N,K", [(3072, 1536, 512), (3072, 2048, 512), (3000, 1540, 512), (2048, 4100, 544), (1540, 3000, 1024),
+                                   (2048, 512, 3072)])
+def test_gemm_f32_many_tiles_exact_integers(M, N, K):
+    """Shapes the fp32 dispatcher gives to the LDS-DMA kernel on a 256-CU part (16-byte aligned rows, K % 32 == 0, at least two
+    of its 64x64 or 32x64 tiles per CU: the temporal transformer at 3 072 tokens, the MoCo projector and logits, the MLM head;
+    reference modules/module_cross.py:114-149, modules/modeling.py:286-313,788-807), with ragged M / N edges, in the orientations
+    of the path and with every epilogue.  Integer-valued operands: every product and partial sum is exact in fp32, so the result
+    must EQUAL the fp64 product.  (scratch/fuzz_f32_dma.py forces the kernel on 150 random shapes per tile size: no mismatch.)"""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
+    b = torch.randint(-3, 4, (N, K), generator=g).float().to(DEV)
+    bias = torch.randint(-5, 6, (N,), generator=g).float().to(DEV)
+    res = torch.randint(-5, 6, (M, N), generator=g).float().to(DEV)
+    ref = (a.double() @ b.double().t()).float()
+    bt, at = b.t().contiguous(), a.t().contiguous()
+    assert torch.equal(ops.gemm_f32(a, b, M, N, K, (K, 1), (1, K)), ref), "x W^T"
+    assert torch.equal(ops.gemm_f32(a, bt, M, N, K, (K, 1), (N, 1), alpha=2.0, bias=bias), 2 * ref + bias), "dy W (+ alpha, bias)"
+    assert torch.equal(ops.gemm_f32(at, bt, M, N, K, (1, M), (N, 1), resid=res), ref + res), "dy^T x (+ residual)"
+    assert torch.equal(ops.gemm_f32(at, b, M, N, K, (1, M), (1, K)), ref), "row-contiguous A, k-contiguous B"
+    assert torch.equal(ops.gemm_f32(a, b, M, N, K, (K, 1), (1, K), bias=bias, epilogue=ops.EPI_RELU), (ref + bias).clamp_min(0)), "ReLU"
+    y, h = ops.gemm_f32(a, b, M, N, K, (K, 1), (1, K), bias=bias, epilogue=ops.EPI_QGELU, want_aux=True)
+    assert torch.equal(h, ref + bias), "saved pre-activation"
+    close(y, h * torch.sigmoid(1.702 * h), 1e-5, 1e-5, "QuickGELU")
+    dy = torch.randint(-3, 4, (M, N), generator=g).float().to(DEV)
+    dx = ops.gemm_f32(a, b, M, N, K, (K, 1), (1, K), aux_in=dy, epilogue=ops.EPI_DGELU)
+    sg = torch.sigmoid(1.702 * dy)
+    close(dx, ref * (sg * (1 + 1.702 * dy * (1 - sg))), 1e-5, 1e-4, "x QuickGELU'(aux)")
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = torch.randn(N, K, generator=g).to(DEV)
+    yr = ops.gemm_f32(x, w, M, N, K, (K, 1), (1, K))
+    close(yr, x.double() @ w.double().t(), 1e-4 * K / 512, 1e-5, "random operands")
+    assert torch.equal(yr, ops.gemm_f32(x, w, M, N, K, (K, 1), (1, K))), "two launches, same bits"
+
+
 @pytest.mark.parametrize("tag", ["head_ft_small", "head_ft_c2"])
 def test_finetune_head_vs_reference_golden(tag):
     g = golden(tag)
