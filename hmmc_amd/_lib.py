@@ -75,6 +75,8 @@ SIGNATURES = {
     "hmmc_mt_sumsq": ("ppipip", "i"),
     "hmmc_mt_clip_grad_norm": ("ppipifpp", "i"),
     "hmmc_mt_bertadam": ("ppipipip", "i"),
+    "hmmc_mt_clip_grad_norm_keep": ("ppipifppp", "i"),
+    "hmmc_mt_bertadam_ext": ("ppipiippp", "i"),
     "hmmc_mt_ema": ("ppiffp", "i"),
     "hmmc_enqueue": ("ppiillp", "i"),
     "hmmc_bn_workspace": ("ii", "z"),

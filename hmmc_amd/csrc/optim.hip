@@ -102,32 +102,47 @@ __global__ __launch_bounds__(256) void mt_clip_coef_kernel(const long* __restric
   }
 }
 
+// part_after (optional): [nchunks] partial sums of squares of the gradient AS WRITTEN (scaled and rounded), accumulated in
+// mt_sumsq_kernel's order, so that the optimizer's per-parameter clip can take its norms from this pass instead of reading
+// every gradient again (hmmc_mt_clip_grad_norm_keep / hmmc_mt_bertadam_ext); with a coefficient of 1 nothing is written to the
+// gradients and the partial sums of the first pass are handed on.
 __global__ __launch_bounds__(256) void mt_scale_kernel(const long* __restrict__ tab, const int* __restrict__ chunk,
-                                                       const float* __restrict__ coef) {
+                                                       const float* __restrict__ coef, const float* __restrict__ part_before,
+                                                       float* __restrict__ part_after) {
   const float c = coef[0];
-  if (c == 1.0f) return;
+  if (c == 1.0f) {
+    if (part_after && threadIdx.x == 0) part_after[blockIdx.x] = part_before[blockIdx.x];
+    return;
+  }
   const int t = chunk[2 * blockIdx.x], ci = chunk[2 * blockIdx.x + 1];
   const long* e = tab + (long)t * 8;
   const long n = e[4];
   const long i0 = (long)ci * CHUNK, i1 = min(n, i0 + CHUNK);
+  float s = 0.f;
   if (e[5] == 0) {
     half_t* g = reinterpret_cast<half_t*>(e[1]);
     const long iv = i0 + ((i1 - i0) & ~7L);
     for (long i = i0 + threadIdx.x * 8; i < iv; i += 256 * 8) {
       h8 v = *reinterpret_cast<h8*>(g + i);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (half_t)opq((float)v[j] * c);
+      for (int j = 0; j < 8; ++j) { v[j] = (half_t)opq((float)v[j] * c); float x = (float)v[j]; s += x * x; }
       *reinterpret_cast<h8*>(g + i) = v;
     }
-    for (long i = iv + threadIdx.x; i < i1; i += 256) g[i] = (half_t)opq((float)g[i] * c);
+    for (long i = iv + threadIdx.x; i < i1; i += 256) { g[i] = (half_t)opq((float)g[i] * c); float x = (float)g[i]; s += x * x; }
   } else {
     float* g = reinterpret_cast<float*>(e[1]);
     const long iv = i0 + ((i1 - i0) & ~3L);
     for (long i = i0 + threadIdx.x * 4; i < iv; i += 256 * 4) {
       f4 v = *reinterpret_cast<f4*>(g + i);
-      *reinterpret_cast<f4*>(g + i) = v * c;
+      v = v * c;
+      *reinterpret_cast<f4*>(g + i) = v;
+      s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
-    for (long i = iv + threadIdx.x; i < i1; i += 256) g[i] = g[i] * c;
+    for (long i = iv + threadIdx.x; i < i1; i += 256) { g[i] = g[i] * c; float x = g[i]; s += x * x; }
+  }
+  if (part_after) {                                   // kernel-argument uniform
+    s = block_sum(s);
+    if (threadIdx.x == 0) part_after[blockIdx.x] = s;
   }
 }
 
@@ -135,9 +150,12 @@ __global__ __launch_bounds__(256) void mt_scale_kernel(const long* __restrict__ 
 constexpr int MAX_GROUPS = 32;
 struct AdamGroups { float v[MAX_GROUPS][8]; };
 
+// index (optional): sumsq is another table's array and tensor t's entry is sumsq[index[t]] (hmmc_mt_bertadam_ext)
 __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict__ tab, AdamGroups groups,
-                                                          const int* __restrict__ chunk, const float* __restrict__ sumsq) {
+                                                          const int* __restrict__ chunk, const float* __restrict__ sumsq_,
+                                                          const int* __restrict__ index) {
   const int t = chunk[2 * blockIdx.x], ci = chunk[2 * blockIdx.x + 1];
+  const float* const sumsq = index ? sumsq_ + index[t] - t : sumsq_;       // sumsq[t] below = the tensor's squared norm
   const long* e = tab + (long)t * 8;
   const float* f = groups.v[e[6]];
   const long n = e[4];
@@ -285,7 +303,23 @@ extern "C" int hmmc_mt_clip_grad_norm(const long* tab, const int* chunk, int nch
   hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq + T);
   hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq);
   hipLaunchKernelGGL(mt_clip_coef_kernel, dim3(1), dim3(256), 0, stream, tab, (const float*)sumsq, T, max_norm, out);
-  hipLaunchKernelGGL(mt_scale_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, (const float*)out);
+  hipLaunchKernelGGL(mt_scale_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, (const float*)out, (const float*)nullptr, (float*)nullptr);
+  return hmmc_launch_status();
+}
+
+// The same, and sumsq_after[0 .. T) = the squared norm of every gradient as it stands AFTER the clip (sumsq_after: float
+// [T + nchunks], laid out like sumsq), formed inside the scaling pass: what BertAdam's per-parameter clip needs next
+// (hmmc_mt_bertadam_ext), without another pass over the gradients.
+extern "C" int hmmc_mt_clip_grad_norm_keep(const long* tab, const int* chunk, int nchunks, float* sumsq, int T, float max_norm,
+                                           float* out, float* sumsq_after, hipStream_t stream) {
+  if (!tab || !chunk || !sumsq || !out || !sumsq_after || nchunks <= 0 || T <= 0) return HMMC_ERR_ARG;
+  hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq + T);
+  hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq);
+  hipLaunchKernelGGL(mt_clip_coef_kernel, dim3(1), dim3(256), 0, stream, tab, (const float*)sumsq, T, max_norm, out);
+  hipLaunchKernelGGL(mt_scale_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, (const float*)out, (const float*)(sumsq + T),
+                     sumsq_after + T);
+  hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq_after + T),
+                     sumsq_after);
   return hmmc_launch_status();
 }
 
@@ -298,7 +332,21 @@ extern "C" int hmmc_mt_bertadam(const long* tab, const float* groups_host, int n
     for (int j = 0; j < 8; ++j) groups.v[g][j] = groups_host[g * 8 + j];
   hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq + T);
   hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq);
-  hipLaunchKernelGGL(mt_bertadam_kernel, dim3(nchunks), dim3(256), 0, stream, tab, groups, chunk, (const float*)sumsq);
+  hipLaunchKernelGGL(mt_bertadam_kernel, dim3(nchunks), dim3(256), 0, stream, tab, groups, chunk, (const float*)sumsq, (const int*)nullptr);
+  return hmmc_launch_status();
+}
+
+// BertAdam.step with the gradients' squared norms supplied: tensor t's is norms[index[t]] (norms = the sumsq_after of the
+// hmmc_mt_clip_grad_norm_keep call that ran on the SAME, since unmodified, gradients; index maps this table's tensors to that
+// call's).  Saves the optimizer's own pass over every gradient.
+extern "C" int hmmc_mt_bertadam_ext(const long* tab, const float* groups_host, int ngroups, const int* chunk, int nchunks, int T,
+                                    const float* norms, const int* index, hipStream_t stream) {
+  if (!tab || !groups_host || !chunk || !norms || !index || nchunks <= 0 || T <= 0) return HMMC_ERR_ARG;
+  if (ngroups <= 0 || ngroups > MAX_GROUPS) return HMMC_ERR_UNSUPPORTED;
+  AdamGroups groups;
+  for (int g = 0; g < ngroups; ++g)
+    for (int j = 0; j < 8; ++j) groups.v[g][j] = groups_host[g * 8 + j];
+  hipLaunchKernelGGL(mt_bertadam_kernel, dim3(nchunks), dim3(256), 0, stream, tab, groups, chunk, norms, index);
   return hmmc_launch_status();
 }
 

@@ -8,6 +8,7 @@ starting at 0 so the first update uses lr 0 under warm-up.
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -16,6 +17,9 @@ from torch.optim import Optimizer
 from torch.optim.optimizer import required
 
 from ._lib import call, load, ptr
+
+
+_NO_SHARED_NORMS = os.environ.get("HMMC_NO_SHARED_NORMS", "0") == "1"      # A/B runs and tests
 
 
 def warmup_cosine(x, warmup=0.002):
@@ -106,12 +110,14 @@ def _dtype_flag(t):
 
 
 _clip_tables = {}
+_pending_norms = {}          # device -> what the last clip_grad_norm_ left for the optimizer (see there)
 
 
 def clip_grad_norm_(parameters, max_norm):
     """torch.nn.utils.clip_grad_norm_(parameters, max_norm) semantics (main_task_retrieval.py:291) in three
     launches over all gradients.  Returns the total norm (0-dim device tensor, no host sync)."""
-    grads = [p.grad for p in parameters if p.grad is not None]
+    plist = [p for p in parameters if p.grad is not None]
+    grads = [p.grad for p in plist]
     if not grads:
         return torch.zeros(())
     dev = grads[0].device
@@ -130,7 +136,17 @@ def clip_grad_norm_(parameters, max_norm):
         raise ValueError("gradients must be contiguous")
     tbl.build(rows)
     out = torch.empty(2, dtype=torch.float32, device=dev)
-    call("hmmc_mt_clip_grad_norm", ptr(tbl.tab), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T, float(max_norm), ptr(out))
+    # The scaling pass also leaves every gradient's squared norm as it stands afterwards: BertAdam's per-parameter clip needs
+    # exactly that next, and would otherwise read every gradient once more (optimization.py:140-150 of the reference calls
+    # clip_grad_norm_ per parameter inside step()).  The hand-over (_pending_norms) names the gradients by address and version
+    # counter, is consumed by the first step() that sees it and ignored by one whose gradients differ in either.
+    if getattr(tbl, "sumsq_after", None) is None or tbl.sumsq_after.numel() != tbl.sumsq.numel():
+        tbl.sumsq_after = torch.zeros_like(tbl.sumsq)
+    call("hmmc_mt_clip_grad_norm_keep", ptr(tbl.tab), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T, float(max_norm), ptr(out),
+         ptr(tbl.sumsq_after))
+    _pending_norms[str(dev)] = {"pids": np.fromiter((id(p) for p in plist), dtype=np.int64, count=n), "ptrs": rows[:, 1].copy(),
+                                "versions": np.fromiter((g._version for g in grads), dtype=np.int64, count=n),
+                                "norms": tbl.sumsq_after, "stream": torch.cuda.current_stream(dev)}
     return out[1]
 
 
@@ -208,10 +224,39 @@ class BertAdam(Optimizer):
         rows[:, 1] = np.fromiter((g.data_ptr() for g in grads), dtype=np.int64, count=len(grads))
         tbl = fp["table"].build(rows)
         hp_host = (ctypes.c_float * len(hp))(*hp)
-        call("hmmc_mt_bertadam", ptr(tbl.tab), hp_host, len(fp["groups"]), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T)
+        index = self._norms_from_clip(fp, rows[:, 1], grads, tbl.device)
+        if index is not None:
+            norms, idx = index
+            call("hmmc_mt_bertadam_ext", ptr(tbl.tab), hp_host, len(fp["groups"]), ptr(tbl.chunk), tbl.nchunks, tbl.T, ptr(norms), ptr(idx))
+        else:
+            call("hmmc_mt_bertadam", ptr(tbl.tab), hp_host, len(fp["groups"]), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T)
         for st in fp["states"]:
             st["step"] += 1
         return True
+
+    @staticmethod
+    def _norms_from_clip(fp, grad_ptrs, grads, device):
+        """(norms, index) when the clip_grad_norm_ call just before this step left the squared norms of exactly these gradients
+        (the same parameters' gradients at the same addresses, version counters unchanged since, same stream): index[t] =
+        position of this table's tensor t in that call's list.  None otherwise - the optimizer then forms the norms itself.
+        The index depends on the two parameter ORDERS only, so it is built (and uploaded) once, not per step: gradient
+        addresses change from step to step.  HMMC_NO_SHARED_NORMS=1 switches the hand-over off."""
+        rec = _pending_norms.pop(str(device), None)            # single use: a later step() never sees a stale hand-over
+        if rec is None or _NO_SHARED_NORMS or rec["stream"] != torch.cuda.current_stream(device):
+            return None
+        cached = fp.get("clip_index")
+        if cached is None or not np.array_equal(cached[0], rec["pids"]):
+            pos = {int(a): i for i, a in enumerate(rec["pids"])}
+            host = np.fromiter((pos.get(id(p), -1) for p in fp["params"]), dtype=np.int64, count=len(fp["params"]))
+            if len(pos) != len(rec["pids"]) or (host < 0).any():
+                return None                                    # a parameter the clip did not see
+            cached = (rec["pids"].copy(), host, torch.from_numpy(host.astype(np.int32)).to(device))
+            fp["clip_index"] = cached
+        host = cached[1]
+        if not (np.array_equal(rec["ptrs"][host], grad_ptrs) and
+                np.array_equal(np.fromiter((g._version for g in grads), dtype=np.int64, count=len(grads)), rec["versions"][host])):
+            return None                                        # another gradient tensor, or one written to after the clip
+        return rec["norms"], cached[2]
 
     def load_state_dict(self, state_dict):
         self._fast, self._table = None, None                  # the cached tables point at the old moment tensors

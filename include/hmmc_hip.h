@@ -283,6 +283,14 @@ int hmmc_mt_clip_grad_norm(const long* tab, const int* chunk, int nchunks, float
 /* BertAdam.step (modules/optimization.py:103-168) for every tensor, including its per-parameter clip. */
 int hmmc_mt_bertadam(const long* tab, const float* groups_host, int ngroups, const int* chunk, int nchunks, float* sumsq,
                      int T, hmmc_stream_t stream);
+/* The pair the training loop's `clip_grad_norm_(...); optimizer.step()` (main_task_retrieval.py:291-296) maps to when both see
+ * the same gradients: the clip also leaves the squared norm of every gradient as it stands after scaling in
+ * sumsq_after[0 .. T) (float [T + nchunks], formed inside the scaling pass), and the optimizer takes tensor t's norm for its
+ * per-parameter clip from norms[index[t]] instead of reading every gradient once more. */
+int hmmc_mt_clip_grad_norm_keep(const long* tab, const int* chunk, int nchunks, float* sumsq, int T, float max_norm, float* out,
+                                float* sumsq_after, hmmc_stream_t stream);
+int hmmc_mt_bertadam_ext(const long* tab, const float* groups_host, int ngroups, const int* chunk, int nchunks, int T,
+                         const float* norms, const int* index, hmmc_stream_t stream);
 /* _momentum_update (modules/modeling.py:238-242); tab rows = {p_k, p, 0, 0, numel, dtype}. */
 int hmmc_mt_ema(const long* tab, const int* chunk, int nchunks, float momentum, float one_minus_momentum,
                 hmmc_stream_t stream);

@@ -754,6 +754,59 @@ def test_clip_grad_norm_follows_the_gradients_it_is_given():
             close(p.grad, r * coef, 1e-6, 2e-3 if dtype == torch.float16 else 1e-5, "clipped gradient")
 
 
+def _clip_and_step(shared, max_norm, scales, touch_after_clip=False, other_stream=False):
+    """One `clip_grad_norm_; optimizer.step()` pair (twice: the first step plans the optimizer's fast path) on a fixed mix of
+    fp16 / fp32 tensors in two parameter groups whose order differs from the order the clip sees; returns every resulting tensor."""
+    from hmmc_amd import optimization
+    from hmmc_amd.optimization import BertAdam, clip_grad_norm_
+    g = torch.Generator().manual_seed(11)
+    sizes = [(40000, torch.float16), (77, torch.float32), (32768, torch.float16), (5, torch.float16), (100003, torch.float32), (4096, torch.float16)]
+    ps = [torch.nn.Parameter((torch.randn(n, generator=g) * 0.1).to(dt).to(DEV)) for n, dt in sizes]
+    groups = [{"params": [ps[3], ps[0], ps[4]], "weight_decay": 0.01}, {"params": [ps[5], ps[1], ps[2]], "weight_decay": 0.0, "lr": 3e-4}]
+    opt = BertAdam(groups, lr=1e-3, warmup=0.1, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6, t_total=50, max_grad_norm=1.0)
+    old = optimization._NO_SHARED_NORMS
+    optimization._NO_SHARED_NORMS = not shared
+    try:
+        for step in range(3):
+            for i, p in enumerate(ps):
+                p.grad = (torch.randn(p.shape, generator=g) * scales[i % len(scales)] * (1 + step)).to(p.dtype).to(DEV)
+            clip_grad_norm_(ps, max_norm)                      # the order of model.parameters(), not the optimizer's
+            if touch_after_clip and step == 2:
+                ps[0].grad.mul_(3.0)                            # a version bump the hand-over must notice
+            if other_stream and step == 2:
+                s2 = torch.cuda.Stream()
+                s2.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s2):
+                    opt.step()
+                torch.cuda.current_stream().wait_stream(s2)
+            else:
+                opt.step()
+    finally:
+        optimization._NO_SHARED_NORMS = old
+    torch.cuda.synchronize()
+    return [t.detach().clone() for p in ps for t in (p, p.grad, opt.state[p]["next_m"], opt.state[p]["next_v"])]
+
+
+@pytest.mark.parametrize("max_norm,scales", [(1.0, (3.0, 0.5)), (1e6, (0.001, 0.0005)), (1e6, (30.0, 0.01)), (0.05, (2.0, 2.0))])
+def test_optimizer_takes_the_norms_the_clip_left_bit_identical(max_norm, scales):
+    """`clip_grad_norm_` hands the per-tensor squared norms of the clipped gradients to the `BertAdam.step()` that follows
+    (reference loop main_task_retrieval.py:291-296; BertAdam clips per parameter inside step(), modules/optimization.py:140-150),
+    which then skips its own pass over every gradient.  Weights, moments and gradients must be BIT-identical to the path that
+    forms the norms itself: global clip active and inactive (coefficient 1: the first pass's sums are handed on), per-parameter
+    clip active (gradient norms > 1 after a no-op global clip) and inactive, fp16 and fp32 tensors, tensor order differing
+    between the two calls; and the hand-over must be dropped when a gradient is written to after the clip or the step runs on
+    another stream."""
+    ref = _clip_and_step(False, max_norm, scales)
+    got = _clip_and_step(True, max_norm, scales)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got)), "shared norms changed a result"
+    ref_t = _clip_and_step(False, max_norm, scales, touch_after_clip=True)
+    got_t = _clip_and_step(True, max_norm, scales, touch_after_clip=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref_t, got_t)), "a gradient modified after the clip must not use the stale norms"
+    assert not all(torch.equal(a, b) for a, b in zip(ref, ref_t)), "(the modification matters)"
+    got_s = _clip_and_step(True, max_norm, scales, other_stream=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got_s)), "step on another stream"
+
+
 @pytest.mark.parametrize("width,heads,L,nseq,causal", [(256, 4, 50, 48, False), (512, 8, 32, 80, True)])
 def test_tower_grouped_weight_gradients_streams_and_oracle(width, heads, L, nseq, causal):
     """A tower backward with enough tokens (>= 2048) and 256-multiple widths takes the grouped weight-gradient launch
