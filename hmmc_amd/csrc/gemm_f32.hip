@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(G32 p) {
 // (LDS side of a DMA is lane-linear, so the XOR is applied to the SOURCE chunk a lane fetches).  As in the kernels above the
 // MFMA's k slot kg of sub-step s is k = 16 kb + 4 kg + s for both operands.
 // Needs 16-byte aligned rows on both operands and K % 32 == 0 (the k tail of a k-contiguous row would read its neighbour).
-template <bool AKC, bool BKC, int MI>
+template <bool AKC, bool BKC, int MI, bool TOPK = false>
 __device__ __forceinline__ void gemm_f32_dma_body(const G32& p, unsigned a_bytes, unsigned b_bytes, int a_fast) {
   constexpr int BM = 32 * MI, BN = 64, BK = 32, NST = 3;
   constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, STAGE = A_BYTES + B_BYTES;
@@ -469,7 +469,16 @@ __device__ __forceinline__ void gemm_f32_dma_body(const G32& p, unsigned a_bytes
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   // tile order: the workgroups resident together walk the SMALLER operand's tiles fastest, so the larger operand's tile is
   // fetched once and shared (the MLM vocabulary projection: 3 MB of activations against 101 MB of weights)
-  const int tm = a_fast ? blockIdx.x % ntm : blockIdx.x / ntn, tn = a_fast ? blockIdx.x / ntm : blockIdx.x % ntn;
+  int tm = a_fast ? blockIdx.x % ntm : blockIdx.x / ntn, tn = a_fast ? blockIdx.x / ntm : blockIdx.x % ntn;
+  if constexpr (TOPK) {
+    // the eval scorer's 15 000 x 48 000 outputs: groups of 16 row tiles, as in gemm_f32_kernel<.., TOPK> (the workgroups resident
+    // together share 16 query tiles and ~48 video tiles instead of one video tile and every query tile)
+    constexpr int GROUP = 16;
+    const int grp = blockIdx.x / (GROUP * ntn), within = blockIdx.x % (GROUP * ntn);
+    const int gm = min(GROUP, ntm - grp * GROUP);
+    tm = grp * GROUP + within % gm;
+    tn = within / gm;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int r = lane & 15, kg = lane >> 4;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)a_bytes, 0x00020000);
@@ -551,6 +560,29 @@ __device__ __forceinline__ void gemm_f32_dma_body(const G32& p, unsigned a_bytes
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[kb][j][s2], a[kb][i][s2], acc[i][j], 0, 0, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the trailing out-of-range loads, before the stages are reused
+  if constexpr (TOPK) {                                           // eval scorer: the epilogue of gemm_f32_kernel<.., TOPK>, same accumulator layout
+    static_assert(!TOPK || MI == 2, "the scorer's epilogue walks 2 x 2 accumulator tiles per wave");
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * (16 * MI) + 16 * i + r;
+      float sv, sf;
+      if (p.tk_P == 16) {                                         // one video per 16-column MFMA tile
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+          topk_video<4>(v, lane, p.tk_F, p.tk_k, sv, sf);
+          topk_emit(p, m, (n0 + wn * 32 + j * 16) >> 4, lane, sv, sf);
+        }
+      } else {                                                    // P == 32: the wave's two tiles are one video
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[i][e >> 2][e & 3] * p.alpha;
+        topk_video<8>(v, lane, p.tk_F, p.tk_k, sv, sf);
+        topk_emit(p, m, (n0 + wn * 32) >> 5, lane, sv, sf);
+      }
+    }
+    return;
+  }
   // Epilogue through LDS: from the MFMA layout (lane = one row, 16 bytes) to lane order (16 consecutive lanes = 256 consecutive
   // bytes of one row), so that the stores - and the residual / auxiliary loads inside store_tile16 - are whole 256-byte row
   // segments instead of 64-byte pieces of 16 different rows per instruction.
@@ -572,6 +604,9 @@ __device__ __forceinline__ void gemm_f32_dma_body(const G32& p, unsigned a_bytes
 template <bool AKC, bool BKC, int MI>
 __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(G32 p, unsigned a_bytes, unsigned b_bytes, int a_fast) {
   gemm_f32_dma_body<AKC, BKC, MI>(p, a_bytes, b_bytes, a_fast);
+}
+__global__ __launch_bounds__(256) void gemm_f32_dma_topk_kernel(G32 p, unsigned a_bytes, unsigned b_bytes) {
+  gemm_f32_dma_body<true, true, 2, true>(p, a_bytes, b_bytes, 0);
 }
 
 // packed[video * P + slot][:] = unit row: slot 0 = visual[video], 1..F = frames[video][slot - 1], slots past F zero
@@ -766,6 +801,15 @@ extern "C" int hmmc_eval_score(const float* queries_unit, const float* packed, f
   p.avec = p.bvec = 1; p.cvec = 0;
   p.tk_F = F; p.tk_P = P; p.tk_k = k; p.tk_nv = nv; p.tk_video = out_video; p.tk_frame = out_frame; p.tk_score = out_score;
   const long blocks = (long)((nq + TM - 1) / TM) * ((p.N + TN - 1) / TN);
+  // the LDS-DMA kernel (same 64x64 tile and accumulator layout: 115-120 against 85-93 TFLOP/s at the VATEX size) where its
+  // conditions hold: whole 32-deep K-steps, 32-bit byte offsets
+  static const bool dma_off = std::getenv("HMMC_NO_F32_DMA") != nullptr;
+  const uint64_t a_ext = (uint64_t)nq * E * 4, b_ext = (uint64_t)p.N * E * 4;
+  if (!dma_off && !(E & 31) && a_ext + 64ull * E * 4 < (1ull << 31) && b_ext + 64ull * E * 4 < (1ull << 31)) {
+    hipLaunchKernelGGL(gemm_f32_dma_topk_kernel, dim3((unsigned)blocks), dim3(256), 3 * (64 + 64) * 32 * 4, stream, p, (unsigned)a_ext,
+                       (unsigned)b_ext);
+    return hmmc_launch_status();
+  }
   hipLaunchKernelGGL((gemm_f32_kernel<OP_KVEC, OP_KVEC, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
   return hmmc_launch_status();
 }
