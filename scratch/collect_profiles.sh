@@ -34,7 +34,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p --output-format csv -- python3 $R/bench.py $CMD > $OUT/pmc_$c.log 2>&1
 done
 python3 $R/scratch/pmc_traffic.py $(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) \
-  $OUT/${TAG}_gemm_f16_hbm_traffic.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py $CMD" 4 > $OUT/traffic.log 2>&1
+  $OUT/${TAG}_gemm_f16_hbm_traffic.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py $CMD" 3 > $OUT/traffic.log 2>&1   # 1 warm-up + 2 timed steps; nothing runs after the timed region with --roofline-steps 0
 # SQ counters of the c_fc forward and the in_proj weight-gradient shapes
 i=0
 for set in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM"; do

@@ -52,3 +52,20 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(RuntimeError, match="no CPU or eager fallback"):
         _lib.load()
+
+
+def test_committed_traffic_record_matches_the_kernel_source_and_the_step_it_was_taken_on():
+    """bench.py reports `roofline.traffic` from the newest profiles/r*_gemm_f16_hbm_traffic.json only if the record was taken on
+    this gemm_f16.hip and counts the launches of the steps it ran (round 4 shipped a record that divided by one step too many
+    after the profiled command lost its trailing step: the bench line would have said `traffic: null`)."""
+    import glob, hashlib, json, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = sorted(glob.glob(os.path.join(root, "profiles", "r*_gemm_f16_hbm_traffic.json")))
+    assert paths, "no committed PMC record"
+    rec = json.load(open(paths[-1]))
+    src = open(os.path.join(root, "hmmc_amd", "csrc", "gemm_f16.hip"), "rb").read()
+    assert rec["gemm_f16_hip_sha256_16"] == hashlib.sha256(src).hexdigest()[:16], "re-collect: scratch/collect_traffic.sh"
+    m_steps, m_warm = re.search(r"--steps (\d+)", rec["command"]), re.search(r"--warmup (\d+)", rec["command"])
+    ran = int(m_steps.group(1)) + int(m_warm.group(1)) + (0 if "--roofline-steps 0" in rec["command"] else 1)
+    assert rec["steps_profiled"] == ran, (rec["steps_profiled"], ran)
+    assert rec["launches"] == rec["launches_per_step"] * rec["steps_profiled"]
