@@ -57,9 +57,30 @@ __device__ __forceinline__ void frags_to_tile(half_t* tile, const h8 (&f)[KT][2]
       *reinterpret_cast<h8*>(tile + (t * 16 + (lane & 15)) * LDS_STRIDE + ks * 32 + 8 * (lane >> 4)) = f[t][ks];
 }
 
-template <int KT>
+// Row 0 of a [L][64] operand in the lane order of load_rows (lanes 0-7: its 128 bytes), every other row of the first 16 as zeros.
+__device__ __forceinline__ void load_lead_row(const half_t* src, u4v (&raw)[2], int lane) {
+  const u4v v = *reinterpret_cast<const u4v*>(src + 8 * (lane & 7));
+  const u4v z = {0u, 0u, 0u, 0u};
+  raw[0] = lane < 8 ? v : z;
+  raw[1] = z;
+}
+// ... -> rows 0..15 of the wave's tile -> the row fragments of tile 0
+__device__ __forceinline__ void lead_to_frags(half_t* tile, const u4v (&raw)[2], h8 (&f)[2], int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    *reinterpret_cast<u4v*>(tile + ((lane >> 3) + 8 * i) * LDS_STRIDE + 8 * (lane & 7)) = raw[i];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) f[ks] = *reinterpret_cast<const h8*>(tile + (lane & 15) * LDS_STRIDE + ks * 32 + 8 * (lane >> 4));
+}
+
+// LEAD: only query 0 of every sequence is wanted (the last block of a tower whose caller reads the class token alone,
+// hmmc_tower_fwd with lead_only): the SAME instruction sequence on query tile 0 with the tile's other fifteen rows as zeros - a
+// query's column of every MFMA is independent of the other columns, so row 0 of the output and its log-sum-exp are bit-identical
+// to the all-query kernel's - and only that row is stored.  The Q columns of the other tokens are never read.
+template <int KT, bool LEAD = false>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
   constexpr int LP = 16 * KT;
+  constexpr int QT = LEAD ? 1 : KT;              // query tiles computed
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -77,14 +98,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 
   // every operand is requested before the first MFMA (rows past L clamped; masked below where it matters); V goes last
   // through the tile, which then holds it for the transposed reads
-  h8 kf[KT][2], qf[KT][2], vf[KT][2];
+  h8 kf[KT][2], qf[QT][2], vf[KT][2];
   {
-    u4v rk[2 * KT], rq[2 * KT], rv[2 * KT];
+    u4v rk[2 * KT], rq[2 * QT], rv[2 * KT];
     load_rows<KT>(k, ld, L, rk, lane);
-    load_rows<KT>(q, ld, L, rq, lane);
+    if constexpr (LEAD) load_lead_row(q, rq, lane); else load_rows<KT>(q, ld, L, rq, lane);
     load_rows<KT>(v, ld, L, rv, lane);
     rows_to_frags<KT>(vtile, rk, kf, lane);
-    rows_to_frags<KT>(vtile, rq, qf, lane);
+    if constexpr (LEAD) lead_to_frags(vtile, rq, qf[0], lane); else rows_to_frags<KT>(vtile, rq, qf, lane);
     rows_to_frags<KT>(vtile, rv, vf, lane);
   }
   h8 vT[4][KT / 2];                              // V^T fragments, k-order permuted like the P^T accumulators
@@ -94,8 +115,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     for (int ks = 0; ks < KT / 2; ++ks) vT[dt][ks] = tr_frag(vtile, ks * 32, ks * 32 + 16, dt * 16, lane);
 
   half_t* o = p.out + (long)n * L * D + h * DH;
+  const int LQ = LEAD ? 1 : L;                   // queries whose results are stored
 #pragma unroll
-  for (int qt = 0; qt < KT; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int qi = qt * 16 + c;
     // S^T[key][q] = sum_d K[key][d] Q[q][d]; lane holds keys kt*16 + 4g + r of query column qi
     f4 s[KT];
@@ -130,7 +152,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (p.lse && g == 0 && qi < L) p.lse[((long)n * p.H + h) * L + qi] = m + __logf(sum);
+    if (p.lse && g == 0 && qi < LQ) p.lse[((long)n * p.H + h) * L + qi] = m + __logf(sum);
     h4 pt[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
       for (int ks = 0; ks < KT / 2; ++ks)
         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vT[dt][ks], cat4(pt[2 * ks], pt[2 * ks + 1]), acc[dt], 0, 0, 0);
     }
-    store_rows(o, D, acc, qt * 16, L, scr, lane);
+    store_rows(o, D, acc, qt * 16, LQ, scr, lane);
   }
 }
 
@@ -162,9 +184,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 //  * One 9 KiB LDS tile per wave, refilled from registers (K, then dO, then Q), serves the three transposed
 //    operands (ds_read_b64_tr_b16); per-query lse / delta are redistributed through 512 B of scratch.
 //  * Outputs leave as 16 B per lane: v_permlane16_swap pairs the d-tiles (2q, 2q+1) so a lane owns 8 consecutive d.
-template <int KT>
+//  * LEAD: the gradient of the output is non-zero for query 0 of every sequence only (hmmc_tower_bwd with lead_only: dout is read
+//    at that row alone, the rest of the buffer may hold anything).  Q and dO enter as tile 0 with fifteen zero rows, every other
+//    query has lse = +inf (probability exactly 0, like the queries past L), phase 1 runs for query tile 0 and phase 2 over the
+//    first pair of query tiles; dK and dV are written for every token, dQ for query 0 only - the Q columns of the other rows
+//    of dqkv are NOT written (their gradient is exactly zero; the tower's data and weight gradients do not read them).
+template <int KT, bool LEAD = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = 16 * KT;
+  constexpr int QT = LEAD ? 1 : KT;              // query tiles with a non-zero output gradient
   constexpr int WAVE_LDS = LP * LDS_STRIDE * 2 + 16 * LDS_STRIDE * 2 + 2 * LP * 4;     // tile + store scratch + lse[LP] + delta[LP]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -189,7 +217,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const float* lse_g = p.lse + ((long)n * p.H + h) * L;
 
   h8 qf[KT][2], kf[KT][2], vf[KT][2], df[KT][2];
-  {
+  if constexpr (LEAD) {
+    u4v rq[2], rk[2 * KT], rv[2 * KT], rd[2];
+    load_lead_row(q, rq, lane);
+    load_rows<KT>(v, ld, L, rv, lane);
+    load_lead_row(dO, rd, lane);
+    load_rows<KT>(k, ld, L, rk, lane);
+    const h8 zf = {};
+#pragma unroll
+    for (int t = 1; t < KT; ++t) { qf[t][0] = zf; qf[t][1] = zf; df[t][0] = zf; df[t][1] = zf; }
+    lead_to_frags(xt, rq, qf[0], lane);
+    rows_to_frags<KT>(xt, rv, vf, lane);
+    lead_to_frags(xt, rd, df[0], lane);
+    rows_to_frags<KT>(xt, rk, kf, lane);       // K last: phase 1 reads K^T from the tile
+  } else {
     u4v rq[2 * KT], rk[2 * KT], rv[2 * KT], rd[2 * KT];
     load_rows<KT>(q, ld, L, rq, lane);
     load_rows<KT>(v, ld, L, rv, lane);
@@ -200,9 +241,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
     rows_to_frags<KT>(xt, rd, df, lane);
     rows_to_frags<KT>(xt, rk, kf, lane);       // K last: phase 1 reads K^T from the tile
   }
-  float lse_c[KT];                               // lse of query qt*16 + c; +inf past L: its probabilities vanish
+  const int LQ = LEAD ? 1 : L;                   // queries with a gradient
+  float lse_c[KT];                               // lse of query qt*16 + c; +inf past LQ: its probabilities vanish
 #pragma unroll
-  for (int t = 0; t < KT; ++t) lse_c[t] = (t * 16 + c < L) ? lse_g[t * 16 + c] : INFINITY;
+  for (int t = 0; t < KT; ++t) lse_c[t] = (t * 16 + c < LQ) ? lse_g[t * 16 + c] : INFINITY;
   if (g == 0) {                                  // exp(x - lse) = exp2(x log2(e) - lse log2(e)): one fma + v_exp_f32 per probability
 #pragma unroll
     for (int t = 0; t < KT; ++t) lse_s[t * 16 + c] = LOG2E * lse_c[t];
@@ -216,8 +258,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   // ---- phase 1: keys on the lane's rows -> delta and dQ (the tile holds K)
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) csum[dt] = f4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (LEAD) {                          // phase 2 reads delta of the first PAIR of query tiles
+    if (g == 0) del_s[16 + c] = 0.f;
+  }
 #pragma unroll
-  for (int qt = 0; qt < KT; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int qi = qt * 16 + c;
     f4 s[KT], dp[KT];
 #pragma unroll
@@ -256,8 +301,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
         acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane),
                                                          cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[dt], 0, 0, 0);
     }
-    store_rows(dq, ld, acc, qt * 16, L, scr, lane, rs[qt]);
-    if (dbias) add_rounded(csum, acc);           // rows past L are exact zeros (their dS is)
+    store_rows(dq, ld, acc, qt * 16, LQ, scr, lane, rs[qt]);
+    if (dbias) add_rounded(csum, acc);           // rows past LQ are exact zeros (their dS is)
   }
   if (dbias) store_colsum(dbias, csum, lane);
 
@@ -277,9 +322,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       const int key = kt * 16 + c;
-      h4 b16[KT];                                // P (pass 0) or dS (pass 1) of key tile kt, [qt]
+      constexpr int QP = LEAD ? 2 : KT;          // query tiles that enter the products (a k-step is a pair of them)
+      h4 b16[QP];                                // P (pass 0) or dS (pass 1) of key tile kt, [qt]
 #pragma unroll
-      for (int qt = 0; qt < KT; ++qt) {
+      for (int qt = 0; qt < QP; ++qt) {
         f4 z = {0.f, 0.f, 0.f, 0.f};
         f4 sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qt][0], kf[kt][0], z, 0, 0, 0);
         sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qt][1], kf[kt][1], sc, 0, 0, 0);
@@ -303,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
       for (int dt = 0; dt < 4; ++dt) {
         acc[dt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KT / 2; ++ks)        // dO^T / Q^T fragments re-read from the tile
+        for (int ks = 0; ks < QP / 2; ++ks)        // dO^T / Q^T fragments re-read from the tile
           acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tr_frag(xt, ks * 32, ks * 32 + 16, dt * 16, lane),
                                                            cat4(b16[2 * ks], b16[2 * ks + 1]), acc[dt], 0, 0, 0);
       }
@@ -372,5 +418,38 @@ static int attention_bwd(const void* qkv, const void* out, const float* lse, con
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
   if (L <= 32) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, 4 * ((32 + 16) * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);
   else hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, block, 4 * ((64 + 16) * LDS_STRIDE * 2 + 2 * 64 * 4), stream, p);
+  return hmmc_launch_status();
+}
+
+// ---- query 0 only (the last block of a tower read at its class token: hmmc_tower_fwd / hmmc_tower_bwd with lead_only) --------
+// out row n*L and lse[(n, h, 0)] of every (sequence, head) - bit-identical to hmmc_attention_f16_fwd's - from the K and V columns of
+// all L tokens and the Q columns of token 0 alone; nothing else of `out` or `lse` is written, no other Q is read.  L <= 64.
+extern "C" int hmmc_attention_f16_fwd_lead(const void* qkv, void* out, float* lse, int nseq, int L, int H, int causal,
+                                           hipStream_t stream) {
+  if (!qkv || !out || !lse || nseq <= 0 || L <= 0 || H <= 0) return HMMC_ERR_ARG;
+  if (L > 64) return HMMC_ERR_UNSUPPORTED;
+  AttnArgs p{};
+  p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = lse; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
+  long pairs = (long)nseq * H;
+  dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
+  if (L <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), grid, block, 4 * (32 + 16) * LDS_STRIDE * 2, stream, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<4, true>), grid, block, 4 * (64 + 16) * LDS_STRIDE * 2, stream, p);
+  return hmmc_launch_status();
+}
+
+// The backward of that: dout is read at row n*L of every sequence only; dqkv receives dK and dV of every token and dQ of token 0
+// (the Q columns of the other rows are left untouched: their gradient is exactly zero); dbias_partial as hmmc_attention_f16_bwd;
+// rowstat (optional) as hmmc_attention_f16_bwd_scaled.
+extern "C" int hmmc_attention_f16_bwd_lead(const void* qkv, const float* lse, const void* dout, void* dqkv, float* dbias_partial,
+                                           const float* rowstat, int nseq, int L, int H, int causal, hipStream_t stream) {
+  if (!qkv || !lse || !dout || !dqkv || nseq <= 0 || L <= 0 || H <= 0) return HMMC_ERR_ARG;
+  if (L > 64) return HMMC_ERR_UNSUPPORTED;
+  AttnArgs p{};
+  p.qkv = (const half_t*)qkv; p.out = nullptr; p.lse = (float*)lse; p.dout = (const half_t*)dout;
+  p.dqkv = (half_t*)dqkv; p.dbias = dbias_partial; p.rowstat = rowstat; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
+  long pairs = (long)nseq * H;
+  dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
+  if (L <= 32) hipLaunchKernelGGL((attn_bwd_kernel<2, true>), grid, block, 4 * ((32 + 16) * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);
+  else hipLaunchKernelGGL((attn_bwd_kernel<4, true>), grid, block, 4 * ((64 + 16) * LDS_STRIDE * 2 + 2 * 64 * 4), stream, p);
   return hmmc_launch_status();
 }

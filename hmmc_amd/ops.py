@@ -439,6 +439,32 @@ def attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=False,
     return (dqkv, part) if want_dbias else dqkv
 
 
+def attention_f16_fwd_lead(qkv, nseq, L, H, causal, out=None, lse=None):
+    """Query 0 of every sequence only: row n*L of `out` and lse[n, h, 0] (the other rows / entries are not written; fresh buffers
+    are filled with NaN so that a consumer of an unwritten row is noticed).  Reads Q at token 0 only."""
+    _chk(qkv, torch.float16, "qkv")
+    D = H * 64
+    assert tuple(qkv.shape) == (nseq * L, 3 * D)
+    if out is None:
+        out = torch.full((nseq * L, D), float("nan"), dtype=torch.float16, device=qkv.device)
+    if lse is None:
+        lse = torch.full((nseq, H, L), float("nan"), dtype=torch.float32, device=qkv.device)
+    call("hmmc_attention_f16_fwd_lead", ptr(qkv), ptr(out), ptr(lse), nseq, L, H, int(causal))
+    return out, lse
+
+
+def attention_f16_bwd_lead(qkv, lse, dout, nseq, L, H, causal, want_dbias=False, rowstat=None, dqkv=None):
+    """Backward of attention_f16_fwd_lead: dout is read at row n*L only; dK, dV of every token and dQ of token 0 are written."""
+    _chk(dout, torch.float16, "dout")
+    if dqkv is None:
+        dqkv = torch.full_like(qkv, float("nan"))
+    part = torch.empty((nseq, qkv.shape[1]), dtype=torch.float32, device=qkv.device) if want_dbias else None
+    if rowstat is not None:
+        _chk(rowstat, torch.float32, "rowstat")
+    call("hmmc_attention_f16_bwd_lead", ptr(qkv), ptr(lse), ptr(dout), ptr(dqkv), ptr(part), ptr(rowstat), nseq, L, H, int(causal))
+    return (dqkv, part) if want_dbias else dqkv
+
+
 # ----------------------------------------------------------------------------- fp32 side
 
 EPI_RELU = 16

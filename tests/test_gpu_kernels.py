@@ -387,6 +387,45 @@ def test_attention_fwd_bwd(nseq, L, H, causal):
     assert float((part - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-4
 
 
+@pytest.mark.parametrize("nseq,L,H,causal", [(5, 50, 2, False), (3, 32, 8, False), (7, 25, 2, True), (4, 64, 12, False), (3, 17, 2, False),
+                                             (96, 50, 12, False)])
+def test_attention_query0_only_equals_the_all_query_kernels(nseq, L, H, causal):
+    """hmmc_attention_f16_fwd_lead / _bwd_lead (the last block of a tower read at its class token, modules/module_cross.py:228-230):
+    row n*L of the output and its log-sum-exp must be BIT-identical to the all-query kernel's, the backward (output gradient at
+    query 0 only, the other rows of the buffer poisoned) must give the all-query kernel's dK, dV, dQ[token 0] and bias partials
+    bit for bit, and nothing but the announced rows may be written or read: the Q columns of the other tokens are NaN on the
+    way in and untouched on the way out."""
+    D = H * 64
+    qkv = rnd(nseq * L, 3 * D, scale=1.0)
+    out, lse = ops.attention_f16_fwd(qkv, nseq, L, H, causal)
+    lead = torch.arange(nseq, device=DEV) * L
+    qkv_p = qkv.clone().view(nseq, L, 3 * D)
+    qkv_p[:, 1:, :D] = float("nan")                                          # only token 0's Q may be read
+    qkv_p = qkv_p.view(nseq * L, 3 * D)
+    out1, lse1 = ops.attention_f16_fwd_lead(qkv_p, nseq, L, H, causal)
+    assert torch.equal(out1[lead], out[lead]), "class-token rows of the output"
+    assert torch.equal(lse1[:, :, 0], lse[:, :, 0]), "their log-sum-exp"
+    rest = torch.ones(nseq * L, dtype=torch.bool, device=DEV); rest[lead] = False
+    assert bool(torch.isnan(out1[rest]).all()) and bool(torch.isnan(lse1[:, :, 1:]).all()), "rows that must not be written"
+    # backward: the reference is the all-query kernel on an output gradient that is zero off the class rows
+    dout = torch.zeros(nseq * L, D, dtype=torch.float16, device=DEV)
+    dout[lead] = rnd(nseq, D, seed=11)
+    dref, pref = ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=True)
+    dout_p = torch.full_like(dout, float("nan")); dout_p[lead] = dout[lead]
+    lse_p = torch.full_like(lse, float("nan")); lse_p[:, :, 0] = lse[:, :, 0]
+    d1, p1 = ops.attention_f16_bwd_lead(qkv_p, lse_p, dout_p, nseq, L, H, causal, want_dbias=True)
+    assert torch.equal(d1[:, D:], dref[:, D:]), "dK, dV of every token"
+    assert torch.equal(d1[lead, :D], dref[lead, :D]), "dQ of the class tokens"
+    assert bool(torch.isnan(d1[rest, :D]).all()), "dQ of the other tokens must stay untouched"
+    assert float(dref[rest, :D].abs().max()) == 0.0, "(and is exactly zero in the all-query computation)"
+    assert torch.equal(p1, pref), "in_proj bias partials"
+    # scaled variant (folded ln_1): rows leave multiplied by their factor
+    stat = torch.rand(nseq * L, 2, device=DEV) + 0.5
+    dsc = ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, rowstat=stat)
+    d2 = ops.attention_f16_bwd_lead(qkv_p, lse_p, dout_p, nseq, L, H, causal, rowstat=stat)
+    assert torch.equal(d2[:, D:], dsc[:, D:]) and torch.equal(d2[lead, :D], dsc[lead, :D]), "scaled rows"
+
+
 def test_retrieval_rank_ties_and_targets():
     """metrics.py:20-28: the rank is the first position of the target's score in the descending sort."""
     torch.manual_seed(3)
