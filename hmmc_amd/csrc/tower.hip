@@ -9,6 +9,7 @@
 //   scratch : hmmc_tower_bwd_scratch_bytes() for the backward's transient gradients
 //   grads   : nlayers x 12 pointers, written (not accumulated)
 #include "common.h"
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -43,6 +44,9 @@ int hmmc_ln_fold_prep(const void* const*, const float* const*, const float* cons
                       const int*, int, int, hipStream_t);
 int hmmc_rowstat(const void*, float*, int, int, long, float, hipStream_t);
 int hmmc_rowstat_finalize(const float*, float*, int, int, int, float, hipStream_t);
+int hmmc_attention_f16_fwd_lead(const void* qkv, void* out, float* lse, int nseq, int L, int H, int causal, hipStream_t stream);
+int hmmc_attention_f16_bwd_lead(const void* qkv, const float* lse, const void* dout, void* dqkv, float* dbias_partial,
+                                const float* rowstat, int nseq, int L, int H, int causal, hipStream_t stream);
 int hmmc_attention_f16_bwd_scaled(const void*, const void*, const float*, const void*, void*, float*, const float*, int, int, int, int,
                                   hipStream_t);
 int hmmc_layernorm_bwd_fold_rows(int);
@@ -120,6 +124,24 @@ inline int wgrad(bool f32, const void* dy, const void* x, void* dw, int T, int N
 
 #define CK(call) do { int rc_ = (call); if (rc_ != 0) return rc_; } while (0)
 
+// The attention half of a LAST block whose caller reads the class token alone (lead_only), sequences of at most 64 tokens: only
+// query 0 of every sequence is wanted, so K | V are projected for every token, Q for the nseq class tokens only (their rows of
+// ln1 / qkv addressed in place at stride L), and the attention runs for that query (hmmc_attention_f16_fwd_lead: bit-identical
+// class rows).  The Q columns of the other rows of qkv, the other rows of att and the other entries of stat are NOT written.
+inline bool lead_attention(bool lead, bool f32, int L) {
+  static const bool off = std::getenv("HMMC_NO_LEAD_ATTN") != nullptr;        // A/B runs: all queries in the last block, as before round 4
+  return lead && !f32 && L <= 64 && !off;
+}
+inline int lead_inproj_attention(const void* ln1, const void* w_in, const void* b_in, void* qkv, void* att, float* stat, long T, int nseq,
+                                 int L, int heads, int D, int causal, hipStream_t s) {
+  const half_t* W = (const half_t*)w_in;
+  const half_t* B = (const half_t*)b_in;
+  CK(hmmc_gemm_f16(ln1, W + (size_t)D * D, (half_t*)qkv + D, (int)T, 2 * D, D, D, D, 3 * D, 1, 1, B + D, nullptr, nullptr, nullptr, EPI_BIAS,
+                   nullptr, 0, s));
+  CK(hmmc_gemm_f16(ln1, W, qkv, nseq, D, D, L * D, D, L * 3 * D, 1, 1, B, nullptr, nullptr, nullptr, EPI_BIAS, nullptr, 0, s));
+  return hmmc_attention_f16_fwd_lead(qkv, att, stat, nseq, L, heads, causal, s);
+}
+
 }  // namespace
 
 extern "C" size_t hmmc_tower_act_bytes(long tokens, int D, int nseq, int L, int heads, int fp32) {
@@ -178,9 +200,11 @@ static size_t general_bytes(long tokens, int D, int fp32) {
     size_t g2 = hmmc_gemm_f16_workspace(4 * D, D, (int)tokens);
     size_t g3 = hmmc_gemm_f16_workspace(D, 4 * D, (int)tokens);
     size_t g4 = hmmc_gemm_f16_workspace(D, D, (int)tokens);
+    size_t g5 = hmmc_gemm_f16_workspace(2 * D, D, (int)tokens);      // K | V rows of in_proj: a lead-only last block
     if (g2 > g) g = g2;
     if (g3 > g) g = g3;
     if (g4 > g) g = g4;
+    if (g5 > g) g = g5;
     if (g > w) w = g;
     size_t grp = group_ws_bytes(tokens, D);          // the grouped launch takes this region when there is no second stream
     if (grp > w) w = grp;
@@ -196,9 +220,11 @@ static size_t wgrad_ws_bytes(long tokens, int D, int fp32) {
   size_t g2 = hmmc_gemm_f16_workspace(4 * D, D, (int)tokens);
   size_t g3 = hmmc_gemm_f16_workspace(D, 4 * D, (int)tokens);
   size_t g4 = hmmc_gemm_f16_workspace(D, D, (int)tokens);
+  size_t g5 = hmmc_gemm_f16_workspace(2 * D, D, (int)tokens);
   if (g2 > g) g = g2;
   if (g3 > g) g = g3;
   if (g4 > g) g = g4;
+  if (g5 > g) g = g5;
   return al(g);
 }
 
@@ -229,9 +255,13 @@ extern "C" int hmmc_tower_fwd(const void* x, void* y, const void* const* params,
     Acts a = carve((char*)acts + (keep_acts ? (size_t)i * slab : 0), T, D, nseq, L, heads, es, f32);
     const void* xin = cur;
     CK(hmmc_layernorm_fwd(xin, (const float*)P[0], (const float*)P[1], a.ln1, a.m1, a.r1, nullptr, (int)T, D, D, eps, dt, s));
-    CK(linear(f32, a.ln1, P[2], a.qkv, (int)T, 3 * D, D, P[3], nullptr, nullptr, 0, workspace, ws_bytes, s));
-    if (f32) CK(hmmc_temporal_attention_fwd((const float*)a.qkv, (float*)a.att, a.stat, nseq, L, heads, causal, s));
-    else CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+    if (lead_attention(lead_only && i + 1 == nlayers, f32, L)) {
+      CK(lead_inproj_attention(a.ln1, P[2], P[3], a.qkv, a.att, a.stat, T, nseq, L, heads, D, causal, s));
+    } else {
+      CK(linear(f32, a.ln1, P[2], a.qkv, (int)T, 3 * D, D, P[3], nullptr, nullptr, 0, workspace, ws_bytes, s));
+      if (f32) CK(hmmc_temporal_attention_fwd((const float*)a.qkv, (float*)a.att, a.stat, nseq, L, heads, causal, s));
+      else CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+    }
     // output of this layer: next layer's saved input slot, or y for the last layer.  Without saved activations one
     // slab is reused: the output alternates between the x and h slots (h is dead once c_proj has read g, and the
     // next layer's input is dead before its own c_fc rewrites h).
@@ -352,8 +382,12 @@ extern "C" int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y,
       const int R = lead ? nseq : (int)T;                 // rows of the per-token half
       const int ldr = lead ? ldl : D;                     // their stride in the [T, D] buffers
       CK(hmmc_layernorm_fwd(xin, (const float*)P[0], (const float*)P[1], a.ln1, a.m1, a.r1, nullptr, (int)T, D, D, eps, 0, s));
-      CK(hmmc_gemm_f16(a.ln1, P[2], a.qkv, (int)T, 3 * D, D, D, D, 3 * D, 1, 1, P[3], nullptr, nullptr, nullptr, EPI_BIAS, nullptr, 0, s));
-      CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+      if (lead_attention(lead, false, L)) {
+        CK(lead_inproj_attention(a.ln1, P[2], P[3], a.qkv, a.att, a.stat, T, nseq, L, heads, D, causal, s));
+      } else {
+        CK(hmmc_gemm_f16(a.ln1, P[2], a.qkv, (int)T, 3 * D, D, D, D, 3 * D, 1, 1, P[3], nullptr, nullptr, nullptr, EPI_BIAS, nullptr, 0, s));
+        CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+      }
       CK(hmmc_gemm_f16(a.att, P[4], a.x1, R, D, D, ldr, D, ldr, 1, 1, P[5], xin, nullptr, nullptr, EPI_BIAS | EPI_RESID, nullptr, 0, s));
       CK(hmmc_layernorm_fwd(a.x1, (const float*)P[6], (const float*)P[7], a.ln2, a.m2, a.r2, nullptr, R, D, ldr, eps, 0, s));
       CK(hmmc_gemm_f16(a.ln2, P[8], a.g, R, 4 * D, D, D, D, 4 * D, 1, 1, P[9], nullptr, keep_acts ? a.h : nullptr, nullptr,
@@ -373,7 +407,10 @@ extern "C" int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y,
     }
     CK(hmmc_gemm_f16_fold(xin, fl[i].w1, a.qkv, (int)T, 3 * D, D, D, D, 3 * D, 1, nullptr, nullptr, nullptr, nullptr, EPI_LNFOLD, st_in, fl[i].cd1,
                           nullptr, nullptr, 0, s));
-    CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+    // (a folded lead-only last block exists in passes without saved activations only: the projection stays whole - its column
+    // terms are one [2][3D] array - and the attention runs for query 0)
+    if (lead_attention(lead, false, L)) CK(hmmc_attention_f16_fwd_lead(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+    else CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
     const int fc_epi = EPI_LNFOLD | EPI_QGELU | (keep_acts ? EPI_SAVE_DGELU : 0);
     void* const fc_aux = keep_acts ? a.h : nullptr;
     if (lead) {
@@ -645,6 +682,34 @@ static int tower_bwd_impl(const void* dy, void* dx, const void* x0, const void* 
       CK(ln_bwd(dln, a.x1, (const float*)P[6], a.m2, a.r2, g_in, dx1, (float*)G[6], (float*)G[7], G[5], nseq, ldl,
                 p_ln2));                                                       // G[5]: out_proj bias = colsum(dx1 rows)
       CK(side_wgrad(2, dx1, a.att, G[4], D, D, nseq, ldl, ldl));
+      if (lead_attention(true, f32, L)) {
+        // The forward ran this block's attention for query 0 only (lead_inproj_attention).  datt exists on the class rows alone
+        // (the rest of dln is not initialised and not read); the attention backward writes dK | dV of every token and dQ of the
+        // class tokens; no gradient reaches the other tokens' Q, so the in_proj weight gradient is (dK | dV)^T ln1 over every
+        // token plus dQ^T ln1 over the class rows, and the data gradient is (dK | dV) W_kv with the class rows recomputed over
+        // the whole of K = 3D (one rounding, as in the all-token pass).
+        CK(hmmc_gemm_f16(dx1, P[4], dln, nseq, D, D, ldl, D, ldl, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, s));
+        CK(before_overwrite(3));
+        CK(hmmc_attention_f16_bwd_lead(a.qkv, a.stat, dln, dqkv, p_attn, nullptr, nseq, L, heads, causal, s));
+        defer(p_attn, nseq, 3 * D, 3 * D, G[3], dt);
+        half_t* const dqkv_h = (half_t*)dqkv;
+        half_t* const gw = (half_t*)G[2];
+        const half_t* const w_in = (const half_t*)P[2];
+        CK(side_wgrad(3, dqkv_h + D, a.ln1, gw + (size_t)D * D, 2 * D, D, (int)T, 3 * D, 0));
+        CK(side_wgrad(3, dqkv_h, a.ln1, gw, D, D, nseq, L * 3 * D, ldl));
+        CK(hmmc_gemm_f16(dqkv_h + D, w_in + (size_t)D * D, dln, (int)T, D, 2 * D, 3 * D, D, D, 1, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                         nullptr, 0, s));
+        CK(hmmc_gemm_f16(dqkv_h, w_in, dln, nseq, D, 3 * D, L * 3 * D, D, ldl, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, s));
+        CK(before_overwrite(0));
+        if (two && gdone_set[par ^ 1]) {
+          if (hipStreamWaitEvent(s, syncp->gdone[par ^ 1], 0) != hipSuccess) return HMMC_ERR_LAUNCH;
+          gdone_set[par ^ 1] = false;
+        }
+        CK(ln_bwd(dln, xin, (const float*)P[0], a.m1, a.r1, dx1, g_out, (float*)G[0], (float*)G[1],
+                  i > 0 ? grads[(size_t)(i - 1) * 12 + 11] : nullptr, (int)T, D, p_ln1));
+        g_in = g_out;
+        continue;
+      }
       if (hipMemsetAsync(dln, 0, (size_t)T * D * es, s) != hipSuccess) return HMMC_ERR_LAUNCH;
       CK(hmmc_gemm_f16(dx1, P[4], dln, nseq, D, D, ldl, D, ldl, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, s));
     } else {
