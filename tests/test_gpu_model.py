@@ -181,14 +181,22 @@ def test_eval_scorer_ranks_identical():
             assert np.array_equal(M.ranks(sv + fk, transposed=True), mo["ranks"]) and mvt["R1"] == mo["R1"]
 
 
-@pytest.mark.parametrize("width,heads,L,nseq,layers", [(128, 2, 10, 37, 3), (768, 12, 50, 96, 2)])
-def test_tower_lead_only_equals_full_tower(width, heads, L, nseq, layers):
-    """hmmc_tower_fwd/bwd with lead_only run the last block's per-token half on the class-token rows alone: those rows of
-    the output, the input gradient and every parameter gradient must equal the full computation's (no gradient reaches the
-    skipped rows; weight gradients differ only in the order of their fp32 partial sums)."""
+@pytest.mark.parametrize("width,heads,L,nseq,layers,fold", [(128, 2, 10, 37, 3, False), (768, 12, 50, 96, 2, False), (768, 12, 50, 96, 3, True),
+                                                            (768, 12, 197, 16, 2, True)])
+def test_tower_lead_only_equals_full_tower(width, heads, L, nseq, layers, fold, monkeypatch):
+    """hmmc_tower_fwd/bwd with lead_only run the last block's per-token half - and, for sequences of at most 64 tokens, its
+    Q projection and attention (round 4) - on the class-token rows alone: those rows of the output must EQUAL the full
+    computation's, the input gradient and every parameter gradient agree with it (no gradient reaches the skipped rows; weight
+    gradients differ only in the order of their fp32 partial sums).  fold: the training path of the frame tower
+    (hmmc_tower_fwd_fused(keep_acts) + hmmc_tower_bwd_fold with the last block on the unfolded kernels); 197 tokens: the
+    long-sequence attention, which keeps the all-query path."""
     from hmmc_amd import module_clip
+    import hmmc_amd.functional as Fn
     torch.manual_seed(3)
     tw = module_clip.Transformer(width, layers, heads)
+    if fold:
+        monkeypatch.setattr(Fn, "_FOLD_LN_TRAIN", "vit")
+        tw.fold_ln = True
     for prm in tw.parameters():
         torch.nn.init.normal_(prm, std=0.05 if prm.dim() > 1 else 0.1)
     for blk in tw.resblocks:
