@@ -56,7 +56,7 @@ SIGNATURES = {
     "hmmc_attention_f16_fwd": ("pppiiiip", "i"),
     "hmmc_attention_f16_bwd": ("ppppppiiiip", "i"),
     "hmmc_attention_f16_fwd_lead": ("pppiiiip", "i"),
-    "hmmc_attention_f16_bwd_lead": ("ppppppiiiip", "i"),
+    "hmmc_attention_f16_bwd_lead": ("pppppppiiiip", "i"),
     "hmmc_gemm_f32": ("pppiiillllifppppip", "i"),
     "hmmc_l2norm_fwd": ("pppiifp", "i"),
     "hmmc_l2norm_bwd": ("ppppiip", "i"),

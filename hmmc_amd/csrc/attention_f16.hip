@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 
 }  // namespace
 
-int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream);
-int hmmc_attention_long_bwd(const AttnArgs& p, hipStream_t stream);
+int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream, bool lead = false);
+int hmmc_attention_long_bwd(const AttnArgs& p, hipStream_t stream, bool lead = false);
 
 extern "C" int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, int nseq, int L, int H, int causal,
                                       hipStream_t stream) {
@@ -427,9 +427,10 @@ static int attention_bwd(const void* qkv, const void* out, const float* lse, con
 extern "C" int hmmc_attention_f16_fwd_lead(const void* qkv, void* out, float* lse, int nseq, int L, int H, int causal,
                                            hipStream_t stream) {
   if (!qkv || !out || !lse || nseq <= 0 || L <= 0 || H <= 0) return HMMC_ERR_ARG;
-  if (L > 64) return HMMC_ERR_UNSUPPORTED;
+  if (L > 256) return HMMC_ERR_UNSUPPORTED;
   AttnArgs p{};
   p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = lse; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
+  if (L > 64) return hmmc_attention_long_fwd(p, stream, true);
   long pairs = (long)nseq * H;
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
   if (L <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), grid, block, 4 * (32 + 16) * LDS_STRIDE * 2, stream, p);
@@ -437,16 +438,19 @@ extern "C" int hmmc_attention_f16_fwd_lead(const void* qkv, void* out, float* ls
   return hmmc_launch_status();
 }
 
-// The backward of that: dout is read at row n*L of every sequence only; dqkv receives dK and dV of every token and dQ of token 0
+// The backward of that: dout (and, for sequences above 64 tokens, out: row n*L of the forward's result) is read at row n*L of
+// every sequence only; dqkv receives dK and dV of every token and dQ of token 0
 // (the Q columns of the other rows are left untouched: their gradient is exactly zero); dbias_partial as hmmc_attention_f16_bwd;
 // rowstat (optional) as hmmc_attention_f16_bwd_scaled.
-extern "C" int hmmc_attention_f16_bwd_lead(const void* qkv, const float* lse, const void* dout, void* dqkv, float* dbias_partial,
-                                           const float* rowstat, int nseq, int L, int H, int causal, hipStream_t stream) {
+extern "C" int hmmc_attention_f16_bwd_lead(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
+                                           float* dbias_partial, const float* rowstat, int nseq, int L, int H, int causal,
+                                           hipStream_t stream) {
   if (!qkv || !lse || !dout || !dqkv || nseq <= 0 || L <= 0 || H <= 0) return HMMC_ERR_ARG;
-  if (L > 64) return HMMC_ERR_UNSUPPORTED;
+  if (L > 256 || (L > 64 && !out)) return HMMC_ERR_UNSUPPORTED;         // the long-sequence kernel forms delta from O (row 0 here)
   AttnArgs p{};
-  p.qkv = (const half_t*)qkv; p.out = nullptr; p.lse = (float*)lse; p.dout = (const half_t*)dout;
+  p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = (float*)lse; p.dout = (const half_t*)dout;
   p.dqkv = (half_t*)dqkv; p.dbias = dbias_partial; p.rowstat = rowstat; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
+  if (L > 64) return hmmc_attention_long_bwd(p, stream, true);
   long pairs = (long)nseq * H;
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
   if (L <= 32) hipLaunchKernelGGL((attn_bwd_kernel<2, true>), grid, block, 4 * ((32 + 16) * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);

@@ -39,7 +39,10 @@ constexpr int fwd_lds_bytes(int KTL, int NW) { return 2 * 16 * KTL * DH * 2 + NW
 // waves per SIMD the register allocation must leave room for: the workgroups the LDS lets a CU hold x NW / 4
 constexpr int fwd_min_waves(int KTL, int NW) { return (160 * 1024 / fwd_lds_bytes(KTL, NW) >= 2 ? 2 : 1) * NW / 4; }
 
-template <int KTL, int NW, bool CAUSAL>
+// LEAD (query 0 of every sequence only, attention_f16.hip): wave 0 runs query tile 0 with the tile's other fifteen rows as zeros -
+// the same instruction sequence as the all-query kernel on that tile, so row 0 and its log-sum-exp are bit-identical - and stores
+// that row alone; the other waves only help bring K and V in.
+template <int KTL, int NW, bool CAUSAL, bool LEAD = false>
 __global__ __launch_bounds__(64 * NW, fwd_min_waves(KTL, NW)) void attn_long_fwd_kernel(AttnArgs p) {
   constexpr int ROWS = 16 * KTL, NT = 64 * NW, RPP = NT / 8, PASSES = (ROWS + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,12 +79,19 @@ __global__ __launch_bounds__(64 * NW, fwd_min_waves(KTL, NW)) void attn_long_fwd
   }
   __syncthreads();
   half_t* o = p.out + (long)n * L * D + h * DH;
-  const int nqt = (L + 15) / 16;
+  const int nqt = LEAD ? 1 : (L + 15) / 16;
+  const int LQ = LEAD ? 1 : L;                   // queries whose results are stored
   // a tile's 16 query rows: lane-ordered loads (requested one tile ahead) -> scratch -> row fragments
   auto load_q = [&](int qt, u4v (&raw)[2]) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-      raw[t] = *reinterpret_cast<const u4v*>(q + (long)min(qt * 16 + (lane >> 3) + 8 * t, L - 1) * ld + 8 * (lane & 7));
+    for (int t = 0; t < 2; ++t) {
+      if constexpr (LEAD) {                      // row 0 alone is read; the tile's other rows are zeros
+        const u4v v0 = *reinterpret_cast<const u4v*>(q + 8 * (lane & 7)), z = {0u, 0u, 0u, 0u};
+        raw[t] = (t == 0 && lane < 8) ? v0 : z;
+      } else {
+        raw[t] = *reinterpret_cast<const u4v*>(q + (long)min(qt * 16 + (lane >> 3) + 8 * t, L - 1) * ld + 8 * (lane & 7));
+      }
+    }
   };
   constexpr float C1 = 0.125f * LOG2E;
   u4v qraw[2], qnext[2];
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(64 * NW, fwd_min_waves(KTL, NW)) void attn_long_fwd
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (g == 0 && qi < L) p.lse[((long)n * p.H + h) * L + qi] = (m2 + __log2f(sum)) * (1.0f / LOG2E);
+    if (g == 0 && qi < LQ) p.lse[((long)n * p.H + h) * L + qi] = (m2 + __log2f(sum)) * (1.0f / LOG2E);
     // O^T[d][q] = sum_key V[key][d] P[q][key]; k-step ks covers key tiles 2ks, 2ks+1 in permuted order
     f4 acc[4];
 #pragma unroll
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(64 * NW, fwd_min_waves(KTL, NW)) void attn_long_fwd
     }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] *= inv;
-    store_rows(o, D, acc, q0, L, scr, lane);
+    store_rows(o, D, acc, q0, LQ, scr, lane);
     qraw[0] = qnext[0]; qraw[1] = qnext[1];
   }
 }
@@ -190,9 +200,15 @@ __device__ __forceinline__ void dma_image(__amdgpu_buffer_rsrc_t rsrc, half_t* i
   }
 }
 
-template <int KTL, int NW, bool CAUSAL>
+// LEAD (the output gradient exists for query 0 of every sequence only; dout is read at that row alone): phase 1 runs for query
+// tile 0 on wave 0 with the tile's other rows as zeros and every other query at lse = +inf (probability exactly 0); the Q and dO
+// images of phase 2 are not fetched - their first 32 rows are written from that tile (row 0 and zeros) - and phase 2 walks the
+// first pair of query tiles only; dK | dV of every token and dQ of token 0 are written, the Q columns of the other rows of dqkv
+// are left untouched.
+template <int KTL, int NW, bool CAUSAL, bool LEAD = false>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(AttnArgs p) {
   constexpr int ROWS = 16 * KTL;
+  constexpr int QPAIRS = LEAD ? 1 : KTL / 2;     // pairs of query tiles phase 2 walks
   static_assert(NW * 2 >= KTL, "a wave holds the K / V fragments of at most two key tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane0 = tid & 63;
@@ -210,6 +226,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
   float* rsc_s = red + 3 * NW * 64;              // [ROWS]: the row factors of the head's tokens (p.rowstat; 1 without)
   const bool want_dbias = p.dbias != nullptr;
   const int nt = (L + 15) / 16;                  // 16-row tiles that hold a real token
+  const int ntq = LEAD ? 1 : nt;                 // ... query tiles with a gradient
+  const int LQ = LEAD ? 1 : L;
   constexpr float C1 = 0.125f * LOG2E;
   const int total = p.nseq * p.H;
   const unsigned ldb = (unsigned)(ld * 2), ldo = (unsigned)(D * 2);
@@ -254,12 +272,13 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
     auto load_tile = [&](int qt) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const long row = min(qt * 16 + (lane >> 3) + 8 * t, L - 1);
+        // LEAD: row 0 is the only row of Q / dO / O that may be read (the same six loads: the counted wait below stands)
+        const long row = LEAD ? 0 : min(qt * 16 + (lane >> 3) + 8 * t, L - 1);
         rq[t] = *reinterpret_cast<const u4v*>(q + row * ld + 8 * (lane & 7));
         rd[t] = *reinterpret_cast<const u4v*>(dO + row * D + 8 * (lane & 7));
         ro[t] = *reinterpret_cast<const u4v*>(o + row * D + 8 * (lane & 7));
       }
-      rl = lse_g[min(qt * 16 + c, L - 1)];
+      rl = lse_g[LEAD ? 0 : min(qt * 16 + c, L - 1)];
       rsv = rs_g[p.rowstat ? 2 * min(qt * 16 + c, L - 1) : 0];
     };
     load_tile(min(wid, nt - 1));                 // requested BEFORE the DMAs below: the in-order vmcnt then does not make the
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
     static_assert(TILE_LOADS == 8, "the wait below leaves TILE_LOADS - 1 loads in flight");
     asm volatile("s_waitcnt vmcnt(7)" ::: "memory");   // all but 7 of those 8 loads: the K / V images of this head (older) have landed
     __syncthreads();
-    {                                            // this head's Q and dO images: needed in phase 2, in flight under phase 1
+    if constexpr (!LEAD) {                       // this head's Q and dO images: needed in phase 2, in flight under phase 1
       dma_image<ROWS, NW>(rsrc_qkv(n), qtile, (unsigned)(h * DH * 2), ldb, wid, lane);
       dma_image<ROWS, NW>(rsrc_dout(n), dtile, (unsigned)(h * DH * 2), ldo, wid, lane);
     }
@@ -284,9 +303,24 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
 #if HMMC_ATTN_SKIP != 0 && !defined(HMMC_SCRATCH)
 #error "HMMC_ATTN_SKIP builds compute wrong results: scratch experiments only (-DHMMC_SCRATCH)"
 #endif
-    for (int qt = wid; qt < nt && HMMC_ATTN_SKIP != 1; qt += NW) {
+    for (int qt = wid; qt < ntq && HMMC_ATTN_SKIP != 1; qt += NW) {
       const int q0 = qt * 16, qi = q0 + c;
       const u4v z = {0u, 0u, 0u, 0u};
+      if constexpr (LEAD) {                      // rows 1..15 of the tile as zeros (every lane loaded row 0)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bool keep = t == 0 && lane < 8;
+          rq[t] = keep ? rq[t] : z; rd[t] = keep ? rd[t] : z; ro[t] = keep ? ro[t] : z;
+        }
+        // the first pair of query tiles of the Q and dO images, from this tile: row 0 and 31 rows of zeros (32 rows x 128 B = 4 KiB
+        // per image; chunk index XORed with swz_tr(row) as the DMA would have placed it)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = (lane >> 3) + 8 * t, ch = (lane & 7) ^ swz_tr(row);
+          *reinterpret_cast<u4v*>(qtile + row * DH + (ch << 3)) = t == 0 ? rq[0] : z;
+          *reinterpret_cast<u4v*>(dtile + row * DH + (ch << 3)) = t == 0 ? rd[0] : z;
+        }
+      }
       // delta and lse of the tile -> LDS (phase 2 reads them for every query), this wave's own values straight from registers
       float dlv[2];
 #pragma unroll
@@ -302,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
         dlv[t] = row < L ? dl : 0.f;
         if ((lane & 7) == 0) del_s[row] = dlv[t];
       }
-      const float lq = qi < L ? LOG2E * rl : INFINITY;          // +inf past L: those queries' probabilities vanish
+      const float lq = qi < LQ ? LOG2E * rl : INFINITY;         // +inf past LQ: those queries' probabilities vanish
       const float sq = p.rowstat ? rsv : 1.0f;                  // row factor of token qi (hmmc_attention_f16_bwd_scaled)
       if (g == 0) { lse_s[qi] = lq; rsc_s[qi] = sq; }
       // rows -> staging tile -> fragments (rows past L as zeros), Q then dO through the same tile (a wave's LDS operations are in order)
@@ -356,14 +390,17 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
                                                            cat4(ds16[2 * ks], ds16[2 * ks + 1]), acc[dt], 0, 0, 0);
         acc[dt] *= 0.125f;
       }
-      if (qt + NW < nt) load_tile(qt + NW);          // the wave's second tile: requested under the dQ stores of the first
-      store_rows(dq, ld, acc, qt * 16, L, scr, lane, sq);
+      if (qt + NW < ntq) load_tile(qt + NW);         // the wave's second tile: requested under the dQ stores of the first
+      store_rows(dq, ld, acc, qt * 16, LQ, scr, lane, sq);
       if (want_dbias) add_rounded(csum, acc);        // queries past L are exact zeros (their dS is)
     }
     if (want_dbias) store_colsum(red + wid * 64, csum, lane);
-    for (int r = nt * 16 + tid; r < ROWS; r += 64 * NW) {     // whole tiles of padding: phase 2 walks every query of the image
+    for (int r = ntq * 16 + tid; r < ROWS; r += 64 * NW) {    // whole tiles without a query: phase 2 walks every query of the image
       lse_s[r] = INFINITY;
       del_s[r] = 0.f;
+    }
+    if constexpr (LEAD) {                        // the row factors of the tokens phase 1 did not visit (phase 2 scales dK / dV by them)
+      for (int r = 16 + tid; r < nt * 16; r += 64 * NW) rsc_s[r] = p.rowstat ? rs_g[2 * min(r, L - 1)] : 1.0f;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the Q / dO images has landed
     __syncthreads();                                          // ... everyone's, and every delta / lse is in LDS
@@ -402,7 +439,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) { av[dt] = f4{0.f, 0.f, 0.f, 0.f}; ak[dt] = f4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-      for (int qp = 0; qp < KTL / 2; ++qp) {
+      for (int qp = 0; qp < QPAIRS; ++qp) {
         h4 p16[2], ds16[2];
         h8 qf[2][2], df[2][2];
         f4 lr[2], dl[2];
@@ -477,65 +514,67 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_long_bwd_kernel(At
 // waves per workgroup: as many as share the head's query tiles evenly in two rounds (197 tokens = 13 tiles: 7 waves), at
 // least 4; two workgroups per CU (unpadded K / V images), i.e. 3 - 4 waves per SIMD to overlap one wave's softmax with
 // another's MFMAs
-template <int KTL, int NW, bool CAUSAL>
+template <int KTL, int NW, bool CAUSAL, bool LEAD>
 static void launch_long_fwd2(const AttnArgs& p, hipStream_t stream) {
   constexpr int LDS = fwd_lds_bytes(KTL, NW);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   if (LDS > 64 * 1024) {
     static bool done[HMMC_MAX_DEVICES] = {false};
-    hmmc_allow_lds((const void*)attn_long_fwd_kernel<KTL, NW, CAUSAL>, LDS, done);
+    hmmc_allow_lds((const void*)attn_long_fwd_kernel<KTL, NW, CAUSAL, LEAD>, LDS, done);
   }
-  hipLaunchKernelGGL((attn_long_fwd_kernel<KTL, NW, CAUSAL>), dim3((unsigned)(p.nseq * p.H)), dim3(64 * NW), LDS, stream, p);
+  hipLaunchKernelGGL((attn_long_fwd_kernel<KTL, NW, CAUSAL, LEAD>), dim3((unsigned)(p.nseq * p.H)), dim3(64 * NW), LDS, stream, p);
 }
 template <int KTL, int NW>
-static void launch_long_fwd(const AttnArgs& p, hipStream_t stream) {
-  if (p.causal) launch_long_fwd2<KTL, NW, true>(p, stream); else launch_long_fwd2<KTL, NW, false>(p, stream);
+static void launch_long_fwd(const AttnArgs& p, hipStream_t stream, bool lead) {
+  if (lead) { if (p.causal) launch_long_fwd2<KTL, NW, true, true>(p, stream); else launch_long_fwd2<KTL, NW, false, true>(p, stream); }
+  else { if (p.causal) launch_long_fwd2<KTL, NW, true, false>(p, stream); else launch_long_fwd2<KTL, NW, false, false>(p, stream); }
 }
 
-int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream) {
+int hmmc_attention_long_fwd(const AttnArgs& p, hipStream_t stream, bool lead) {
   if ((long)p.nseq * p.H >= (1l << 31)) return HMMC_ERR_UNSUPPORTED;
   const int ktl = ((p.L + 31) / 32) * 2;                                    // key tiles, rounded up to an even count
   switch (ktl) {
-    case 6: launch_long_fwd<6, 4>(p, stream); break;       // <= 96 tokens: 5-6 query tiles
-    case 8: launch_long_fwd<8, 4>(p, stream); break;
-    case 10: launch_long_fwd<10, 5>(p, stream); break;
-    case 12: launch_long_fwd<12, 6>(p, stream); break;
-    case 14: launch_long_fwd<14, 7>(p, stream); break;     // 197 tokens (ViT-B/16): 13 tiles on 7 waves
-    case 16: launch_long_fwd<16, 8>(p, stream); break;
+    case 6: launch_long_fwd<6, 4>(p, stream, lead); break;       // <= 96 tokens: 5-6 query tiles
+    case 8: launch_long_fwd<8, 4>(p, stream, lead); break;
+    case 10: launch_long_fwd<10, 5>(p, stream, lead); break;
+    case 12: launch_long_fwd<12, 6>(p, stream, lead); break;
+    case 14: launch_long_fwd<14, 7>(p, stream, lead); break;     // 197 tokens (ViT-B/16): 13 tiles on 7 waves
+    case 16: launch_long_fwd<16, 8>(p, stream, lead); break;
     default: return HMMC_ERR_UNSUPPORTED;
   }
   return hmmc_launch_status();
 }
 
-template <int KTL, int NW, bool CAUSAL>
+template <int KTL, int NW, bool CAUSAL, bool LEAD>
 static void launch_long_bwd2(const AttnArgs& p, hipStream_t stream) {
   constexpr int LDS = 4 * 16 * KTL * DH * 2 + NW * 16 * LDS_STRIDE * 2 + 2 * 16 * KTL * 4   // K, V, Q, dO images + staging per wave + lse, delta
                       + 3 * NW * 64 * 4 + 16 * KTL * 4;                                  // + the waves' column sums + the row factors
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static bool done[HMMC_MAX_DEVICES] = {false};
-  hmmc_allow_lds((const void*)attn_long_bwd_kernel<KTL, NW, CAUSAL>, LDS, done);
+  hmmc_allow_lds((const void*)attn_long_bwd_kernel<KTL, NW, CAUSAL, LEAD>, LDS, done);
   const long total = (long)p.nseq * p.H;
   const long wgs = hmmc_num_cus();                                         // persistent: one workgroup per CU
-  hipLaunchKernelGGL((attn_long_bwd_kernel<KTL, NW, CAUSAL>), dim3((unsigned)(total < wgs ? total : wgs)), dim3(64 * NW), LDS, stream, p);
+  hipLaunchKernelGGL((attn_long_bwd_kernel<KTL, NW, CAUSAL, LEAD>), dim3((unsigned)(total < wgs ? total : wgs)), dim3(64 * NW), LDS, stream, p);
 }
 template <int KTL, int NW>
-static void launch_long_bwd(const AttnArgs& p, hipStream_t stream) {
-  if (p.causal) launch_long_bwd2<KTL, NW, true>(p, stream); else launch_long_bwd2<KTL, NW, false>(p, stream);
+static void launch_long_bwd(const AttnArgs& p, hipStream_t stream, bool lead) {
+  if (lead) { if (p.causal) launch_long_bwd2<KTL, NW, true, true>(p, stream); else launch_long_bwd2<KTL, NW, false, true>(p, stream); }
+  else { if (p.causal) launch_long_bwd2<KTL, NW, true, false>(p, stream); else launch_long_bwd2<KTL, NW, false, false>(p, stream); }
 }
 
-int hmmc_attention_long_bwd(const AttnArgs& p, hipStream_t stream) {
+int hmmc_attention_long_bwd(const AttnArgs& p, hipStream_t stream, bool lead) {
   if ((long)p.nseq * p.H >= (1l << 31) || !p.out) return HMMC_ERR_UNSUPPORTED;
   const int ktl = ((p.L + 31) / 32) * 2;
   switch (ktl) {
     // 8 waves (two per SIMD, up to 256 registers each: phase 2 holds 64 accumulator + 64 transposed-operand registers).  One wave
     // per tile - 13 waves for ViT-B/16's 13 tiles - would need 128 registers per wave and spills ~100 of them; 7 waves (13 tiles
     // in two even rounds) measured the same as 8 (480 vs 487 us at 384 x 197 x 12).
-    case 6: launch_long_bwd<6, 8>(p, stream); break;
-    case 8: launch_long_bwd<8, 8>(p, stream); break;
-    case 10: launch_long_bwd<10, 8>(p, stream); break;
-    case 12: launch_long_bwd<12, 8>(p, stream); break;
-    case 14: launch_long_bwd<14, 8>(p, stream); break;
-    case 16: launch_long_bwd<16, 8>(p, stream); break;
+    case 6: launch_long_bwd<6, 8>(p, stream, lead); break;
+    case 8: launch_long_bwd<8, 8>(p, stream, lead); break;
+    case 10: launch_long_bwd<10, 8>(p, stream, lead); break;
+    case 12: launch_long_bwd<12, 8>(p, stream, lead); break;
+    case 14: launch_long_bwd<14, 8>(p, stream, lead); break;
+    case 16: launch_long_bwd<16, 8>(p, stream, lead); break;
     default: return HMMC_ERR_UNSUPPORTED;
   }
   return hmmc_launch_status();

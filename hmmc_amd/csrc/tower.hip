@@ -45,7 +45,7 @@ int hmmc_ln_fold_prep(const void* const*, const float* const*, const float* cons
 int hmmc_rowstat(const void*, float*, int, int, long, float, hipStream_t);
 int hmmc_rowstat_finalize(const float*, float*, int, int, int, float, hipStream_t);
 int hmmc_attention_f16_fwd_lead(const void* qkv, void* out, float* lse, int nseq, int L, int H, int causal, hipStream_t stream);
-int hmmc_attention_f16_bwd_lead(const void* qkv, const float* lse, const void* dout, void* dqkv, float* dbias_partial,
+int hmmc_attention_f16_bwd_lead(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, float* dbias_partial,
                                 const float* rowstat, int nseq, int L, int H, int causal, hipStream_t stream);
 int hmmc_attention_f16_bwd_scaled(const void*, const void*, const float*, const void*, void*, float*, const float*, int, int, int, int,
                                   hipStream_t);
@@ -124,13 +124,13 @@ inline int wgrad(bool f32, const void* dy, const void* x, void* dw, int T, int N
 
 #define CK(call) do { int rc_ = (call); if (rc_ != 0) return rc_; } while (0)
 
-// The attention half of a LAST block whose caller reads the class token alone (lead_only), sequences of at most 64 tokens: only
+// The attention half of a LAST block whose caller reads the class token alone (lead_only), sequences of at most 256 tokens: only
 // query 0 of every sequence is wanted, so K | V are projected for every token, Q for the nseq class tokens only (their rows of
 // ln1 / qkv addressed in place at stride L), and the attention runs for that query (hmmc_attention_f16_fwd_lead: bit-identical
 // class rows).  The Q columns of the other rows of qkv, the other rows of att and the other entries of stat are NOT written.
 inline bool lead_attention(bool lead, bool f32, int L) {
   static const bool off = std::getenv("HMMC_NO_LEAD_ATTN") != nullptr;        // A/B runs: all queries in the last block, as before round 4
-  return lead && !f32 && L <= 64 && !off;
+  return lead && !f32 && L <= 256 && !off;
 }
 inline int lead_inproj_attention(const void* ln1, const void* w_in, const void* b_in, void* qkv, void* att, float* stat, long T, int nseq,
                                  int L, int heads, int D, int causal, hipStream_t s) {
@@ -690,7 +690,7 @@ static int tower_bwd_impl(const void* dy, void* dx, const void* x0, const void* 
         // the whole of K = 3D (one rounding, as in the all-token pass).
         CK(hmmc_gemm_f16(dx1, P[4], dln, nseq, D, D, ldl, D, ldl, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, s));
         CK(before_overwrite(3));
-        CK(hmmc_attention_f16_bwd_lead(a.qkv, a.stat, dln, dqkv, p_attn, nullptr, nseq, L, heads, causal, s));
+        CK(hmmc_attention_f16_bwd_lead(a.qkv, a.att, a.stat, dln, dqkv, p_attn, nullptr, nseq, L, heads, causal, s));
         defer(p_attn, nseq, 3 * D, 3 * D, G[3], dt);
         half_t* const dqkv_h = (half_t*)dqkv;
         half_t* const gw = (half_t*)G[2];

@@ -453,15 +453,16 @@ def attention_f16_fwd_lead(qkv, nseq, L, H, causal, out=None, lse=None):
     return out, lse
 
 
-def attention_f16_bwd_lead(qkv, lse, dout, nseq, L, H, causal, want_dbias=False, rowstat=None, dqkv=None):
-    """Backward of attention_f16_fwd_lead: dout is read at row n*L only; dK, dV of every token and dQ of token 0 are written."""
+def attention_f16_bwd_lead(qkv, lse, dout, nseq, L, H, causal, want_dbias=False, rowstat=None, dqkv=None, out=None):
+    """Backward of attention_f16_fwd_lead: dout (and out, needed above 64 tokens) is read at row n*L only; dK, dV of every token
+    and dQ of token 0 are written."""
     _chk(dout, torch.float16, "dout")
     if dqkv is None:
         dqkv = torch.full_like(qkv, float("nan"))
     part = torch.empty((nseq, qkv.shape[1]), dtype=torch.float32, device=qkv.device) if want_dbias else None
     if rowstat is not None:
         _chk(rowstat, torch.float32, "rowstat")
-    call("hmmc_attention_f16_bwd_lead", ptr(qkv), ptr(lse), ptr(dout), ptr(dqkv), ptr(part), ptr(rowstat), nseq, L, H, int(causal))
+    call("hmmc_attention_f16_bwd_lead", ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), ptr(part), ptr(rowstat), nseq, L, H, int(causal))
     return (dqkv, part) if want_dbias else dqkv
 
 

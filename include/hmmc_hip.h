@@ -204,11 +204,11 @@ int hmmc_attention_f16_bwd_scaled(const void* qkv, const void* out, const float*
  * takes hidden[:, 0, :]; hmmc_tower_fwd / hmmc_tower_bwd with lead_only).  Forward: out row n*L and lse[(n, h, 0)], bit-identical to
  * hmmc_attention_f16_fwd's, from K and V of all L tokens and Q of token 0; no other row of out / lse is written, no other Q is
  * read.  Backward: dout is read at row n*L only; dK and dV of every token and dQ of token 0 are written (the Q columns of the
- * other rows of dqkv are left untouched: their gradient is exactly zero); rowstat optional, as hmmc_attention_f16_bwd_scaled.
- * L <= 64. */
+ * other rows of dqkv are left untouched: their gradient is exactly zero); rowstat optional, as hmmc_attention_f16_bwd_scaled;
+ * out (the forward's result, read at row n*L only) is needed above 64 tokens.  L <= 256. */
 int hmmc_attention_f16_fwd_lead(const void* qkv, void* out, float* lse, int nseq, int L, int H, int causal, hmmc_stream_t stream);
-int hmmc_attention_f16_bwd_lead(const void* qkv, const float* lse, const void* dout, void* dqkv, float* dbias_partial,
-                                const float* rowstat, int nseq, int L, int H, int causal, hmmc_stream_t stream);
+int hmmc_attention_f16_bwd_lead(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv,
+                                float* dbias_partial, const float* rowstat, int nseq, int L, int H, int causal, hmmc_stream_t stream);
 
 /* fp32 MFMA GEMM (exact f32 FMA chain) with general strides: C[m][n] = epi(alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]);
  * one stride of each operand must be 1.  Epilogue flags as hmmc_gemm_f16 plus HMMC_EPI_RELU; QuickGELU is evaluated in fp32.

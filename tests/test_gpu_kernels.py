@@ -388,7 +388,8 @@ def test_attention_fwd_bwd(nseq, L, H, causal):
 
 
 @pytest.mark.parametrize("nseq,L,H,causal", [(5, 50, 2, False), (3, 32, 8, False), (7, 25, 2, True), (4, 64, 12, False), (3, 17, 2, False),
-                                             (96, 50, 12, False)])
+                                             (96, 50, 12, False), (5, 197, 12, False), (3, 77, 8, True), (2, 130, 2, False), (1, 256, 1, False),
+                                             (300, 197, 12, False)])   # the last: more heads than the persistent grid has workgroups
 def test_attention_query0_only_equals_the_all_query_kernels(nseq, L, H, causal):
     """hmmc_attention_f16_fwd_lead / _bwd_lead (the last block of a tower read at its class token, modules/module_cross.py:228-230):
     row n*L of the output and its log-sum-exp must be BIT-identical to the all-query kernel's, the backward (output gradient at
@@ -413,7 +414,8 @@ def test_attention_query0_only_equals_the_all_query_kernels(nseq, L, H, causal):
     dref, pref = ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, want_dbias=True)
     dout_p = torch.full_like(dout, float("nan")); dout_p[lead] = dout[lead]
     lse_p = torch.full_like(lse, float("nan")); lse_p[:, :, 0] = lse[:, :, 0]
-    d1, p1 = ops.attention_f16_bwd_lead(qkv_p, lse_p, dout_p, nseq, L, H, causal, want_dbias=True)
+    out_p = torch.full_like(out, float("nan")); out_p[lead] = out[lead]      # the long-sequence kernel reads O at the class rows
+    d1, p1 = ops.attention_f16_bwd_lead(qkv_p, lse_p, dout_p, nseq, L, H, causal, want_dbias=True, out=out_p)
     assert torch.equal(d1[:, D:], dref[:, D:]), "dK, dV of every token"
     assert torch.equal(d1[lead, :D], dref[lead, :D]), "dQ of the class tokens"
     assert bool(torch.isnan(d1[rest, :D]).all()), "dQ of the other tokens must stay untouched"
@@ -422,7 +424,7 @@ def test_attention_query0_only_equals_the_all_query_kernels(nseq, L, H, causal):
     # scaled variant (folded ln_1): rows leave multiplied by their factor
     stat = torch.rand(nseq * L, 2, device=DEV) + 0.5
     dsc = ops.attention_f16_bwd(qkv, out, lse, dout, nseq, L, H, causal, rowstat=stat)
-    d2 = ops.attention_f16_bwd_lead(qkv_p, lse_p, dout_p, nseq, L, H, causal, rowstat=stat)
+    d2 = ops.attention_f16_bwd_lead(qkv_p, lse_p, dout_p, nseq, L, H, causal, rowstat=stat, out=out_p)
     assert torch.equal(d2[:, D:], dsc[:, D:]) and torch.equal(d2[lead, :D], dsc[lead, :D]), "scaled rows"
 
 
