@@ -389,7 +389,8 @@ def test_attention_fwd_bwd(nseq, L, H, causal):
 
 @pytest.mark.parametrize("nseq,L,H,causal", [(5, 50, 2, False), (3, 32, 8, False), (7, 25, 2, True), (4, 64, 12, False), (3, 17, 2, False),
                                              (96, 50, 12, False), (5, 197, 12, False), (3, 77, 8, True), (2, 130, 2, False), (1, 256, 1, False),
-                                             (300, 197, 12, False)])   # the last: more heads than the persistent grid has workgroups
+                                             (300, 197, 12, False),    # more heads than the persistent grid has workgroups
+                                             (3072, 50, 12, False)])   # BASELINE config 2's frame tower: 256 videos x 12 frames
 def test_attention_query0_only_equals_the_all_query_kernels(nseq, L, H, causal):
     """hmmc_attention_f16_fwd_lead / _bwd_lead (the last block of a tower read at its class token, modules/module_cross.py:228-230):
     row n*L of the output and its log-sum-exp must be BIT-identical to the all-query kernel's, the backward (output gradient at
