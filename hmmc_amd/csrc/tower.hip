@@ -405,12 +405,33 @@ extern "C" int hmmc_tower_fwd_fused(const void* x, const float* x_stat, void* y,
       else if (x_stat) { if (hipMemcpyAsync(stat1, x_stat, (size_t)T * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) return HMMC_ERR_LAUNCH; }
       else CK(hmmc_rowstat(x, stat1, (int)T, D, D, eps, s));
     }
-    CK(hmmc_gemm_f16_fold(xin, fl[i].w1, a.qkv, (int)T, 3 * D, D, D, D, 3 * D, 1, nullptr, nullptr, nullptr, nullptr, EPI_LNFOLD, st_in, fl[i].cd1,
-                          nullptr, nullptr, 0, s));
-    // (a folded lead-only last block exists in passes without saved activations only: the projection stays whole - its column
-    // terms are one [2][3D] array - and the attention runs for query 0)
-    if (lead_attention(lead, false, L)) CK(hmmc_attention_f16_fwd_lead(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
-    else CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+    if (!lead_attention(lead, false, L)) {
+      CK(hmmc_gemm_f16_fold(xin, fl[i].w1, a.qkv, (int)T, 3 * D, D, D, D, 3 * D, 1, nullptr, nullptr, nullptr, nullptr, EPI_LNFOLD, st_in, fl[i].cd1,
+                            nullptr, nullptr, 0, s));
+      CK(hmmc_attention_f16_fwd(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+    } else {
+      // A folded lead-only last block (passes without saved activations): K | V for every token, Q for the class rows, as
+      // lead_inproj_attention.  The folded GEMM takes its column terms as one [2][N] array and its row pairs per GEMM row, so the
+      // two sub-problems get copies: (c | d) of columns D..3D and of columns 0..D, and the class rows' pairs gathered from
+      // stride L - into the partial-statistics buffer, which is idle until this block's out_proj writes it.
+      float* const cd_kv = fw.part;                       // [2][2D]
+      float* const cd_q = cd_kv + 4 * D;                  // [2][D]
+      float* const st_q = cd_q + 2 * D;                   // [nseq][2]
+      const size_t fb = sizeof(float);
+      if ((size_t)(6 * D + 2 * nseq) > (size_t)nparts * T * 2) return HMMC_ERR_WORKSPACE;
+      if (hipMemcpyAsync(cd_kv, fl[i].cd1 + D, 2 * D * fb, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipMemcpyAsync(cd_kv + 2 * D, fl[i].cd1 + 3 * D + D, 2 * D * fb, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipMemcpyAsync(cd_q, fl[i].cd1, D * fb, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipMemcpyAsync(cd_q + D, fl[i].cd1 + 3 * D, D * fb, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipMemcpy2DAsync(st_q, 2 * fb, st_in, (size_t)L * 2 * fb, 2 * fb, nseq, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return HMMC_ERR_LAUNCH;
+      const half_t* const w1 = (const half_t*)fl[i].w1;
+      CK(hmmc_gemm_f16_fold(xin, w1 + (size_t)D * D, (half_t*)a.qkv + D, (int)T, 2 * D, D, D, D, 3 * D, 1, nullptr, nullptr, nullptr, nullptr,
+                            EPI_LNFOLD, st_in, cd_kv, nullptr, nullptr, 0, s));
+      CK(hmmc_gemm_f16_fold(xin, w1, a.qkv, nseq, D, D, ldl, D, L * 3 * D, 1, nullptr, nullptr, nullptr, nullptr, EPI_LNFOLD, st_q, cd_q, nullptr,
+                            nullptr, 0, s));
+      CK(hmmc_attention_f16_fwd_lead(a.qkv, a.att, a.stat, nseq, L, heads, causal, s));
+    }
     const int fc_epi = EPI_LNFOLD | EPI_QGELU | (keep_acts ? EPI_SAVE_DGELU : 0);
     void* const fc_aux = keep_acts ? a.h : nullptr;
     if (lead) {
