@@ -43,3 +43,8 @@ for set in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_
 done
 python3 $R/scratch/pmc_summary.py $(find /tmp/sq1 /tmp/sq2 /tmp/sq3 -name "*counter_collection.csv") > $OUT/${TAG}_gemm_f16_sq_counters.txt 2>&1
 ls -la $OUT
+# eval leg (fused scorer): kernel stats of bench.py --mode eval
+cd /tmp
+rm -rf /tmp/prof_eval
+rocprofv3 --kernel-trace --stats -d /tmp/prof_eval -o t --output-format csv -- python3 $R/bench.py --mode eval --frames 24 --no-cpu-baseline > $OUT/${TAG}_bench_eval_f24_kernel_stats.log 2>&1
+cp $(find /tmp/prof_eval -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_eval_f24_kernel_stats.csv
