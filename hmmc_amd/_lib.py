@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMMC_LIB") or os.path.join(_HERE, "libhmmc_hip.so")     # HMMC_LIB: a variant build (A/B runs, scratch/)
 
-_C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "z": ctypes.c_size_t}
+_C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "z": ctypes.c_size_t, "s": ctypes.c_char_p}
 
 # name -> (argument codes, return code); must match include/hmmc_hip.h
 SIGNATURES = {
@@ -99,7 +99,30 @@ SIGNATURES = {
     "hmmc_tower_workspace_bytes": ("liiii", "z"),
     "hmmc_tower_fwd": ("ppppiiiiiiifiipzp", "i"),
     "hmmc_tower_bwd": ("pppppppiiiiiiiipzpp", "i"),
+    "hmmc_tower_release": ("pp", "i"),
+    "hmmc_set_option": ("si", "i"),
+    "hmmc_get_option": ("s", "i"),
 }
+
+# The library reads no environment variable itself (include/hmmc_hip.h: hmmc_set_option).  These A/B switches of scratch/ runs
+# and tests are translated once, when the library is loaded; a variable that is PRESENT (any value, the empty string included)
+# switches its option on - the same rule hmmc_amd/functional.py applies on its side.
+ENV_OPTIONS = {"HMMC_NO_WGRAD_GROUP": "no_wgrad_group", "HMMC_NO_F32_WAVEK": "no_f32_wavek", "HMMC_NO_F32_DMA": "no_f32_dma",
+               "HMMC_NO_LEAD_ATTN": "no_lead_attn"}
+
+
+def set_option(key, value):
+    """hmmc_set_option(key, value): process-wide A/B switch of the library (see ENV_OPTIONS for the keys)."""
+    rc = load().hmmc_set_option(key.encode(), int(bool(value)))
+    if rc != 0:
+        raise KeyError(f"hmmc_set_option: unknown option {key!r}")
+
+
+def get_option(key):
+    rc = load().hmmc_get_option(key.encode())
+    if rc < 0:
+        raise KeyError(f"hmmc_get_option: unknown option {key!r}")
+    return bool(rc)
 
 ERRORS = {-1: "invalid argument", -2: "unsupported shape/alignment", -3: "workspace too small", -4: "kernel launch failed"}
 
@@ -119,6 +142,9 @@ def load():
             fn.argtypes = [_C[c] for c in args]
             fn.restype = _C[ret]
         _lib = lib
+        for var, key in ENV_OPTIONS.items():
+            if var in os.environ:
+                lib.hmmc_set_option(key.encode(), 1)
     return _lib
 
 

@@ -23,6 +23,7 @@
 // ds_read_b64_tr_b16 hardware transpose).  Two LDS stages; the prefetch of tile t+1 stays in
 // flight across the compute of tile t (counted vmcnt + raw s_barrier).
 #include "common.h"
+#include "options.h"
 #include <cstdlib>
 
 #ifndef HMMC_DBG
@@ -35,6 +36,9 @@
 #endif
 #ifndef HMMC_PF
 #define HMMC_PF 6     // prefetch distance of the 256x256 K-loop in half-tiles (scratch experiments build 4)
+#endif
+#if (HMMC_DBG != 0 || HMMC_PHASES != 2 || HMMC_PF != 6) && !defined(HMMC_SCRATCH)
+#error "HMMC_DBG / HMMC_PHASES / HMMC_PF other than the product values (0 / 2 / 6) are scratch experiments: build with -DHMMC_SCRATCH"
 #endif
 
 namespace {
@@ -1213,8 +1217,7 @@ GroupPlan group_plan(const int* Np, const int* Kp, int nprob, int T) {
   return g;
 }
 bool group_ok(const int* Np, const int* Kp, int nprob, int T) {
-  static const bool off = std::getenv("HMMC_NO_WGRAD_GROUP") != nullptr;       // A/B runs: one launch per gradient, as before round 3
-  if (off) return false;
+  if (hmmc_option(HMMC_OPT_NO_WGRAD_GROUP)) return false;       // A/B runs: one launch per gradient, as before round 3
   if (!Np || !Kp || nprob < 1 || nprob > GROUP_MAX || T < 2048) return false;
   for (int j = 0; j < nprob; ++j) {
     if (Np[j] < 256 || Kp[j] < 256 || (Np[j] % 256) || (Kp[j] % 256)) return false;       // 256x256 tiles only

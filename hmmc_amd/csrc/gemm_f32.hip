@@ -10,6 +10,7 @@
 // 64x64x16 block tile, 4 waves (2x2, 32x32 each), register-staged double buffering; MFMA operands
 // swapped (A-operand = B rows) so a lane owns 4 consecutive n of one row: 16-byte stores.
 #include "common.h"
+#include "options.h"
 #include <cstdlib>
 
 namespace {
@@ -683,7 +684,7 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
   // (scratch/gemm32_pick.py): ahead for K >= 1536 (data / weight gradients and c_proj of the temporal transformer, the MoCo
   // query gradient, the MLM data gradient), behind for K = 512, where the fixed ~6 us of fill and reduction decide.
   {
-    static const bool off = std::getenv("HMMC_NO_F32_WAVEK") != nullptr;          // A/B runs
+    const bool off = hmmc_option(HMMC_OPT_NO_F32_WAVEK);                          // A/B runs
 #ifdef HMMC_SCRATCH      // scratch/gemm32_pick.py builds: HMMC_F32_PICK = 1 small, 2 tiled, 3.. wave-split-K RM = 2, 3, 4, 6,
     static const char* force_s = std::getenv("HMMC_F32_PICK");                    // 7 / 9 LDS-DMA 64x64 / 32x64
     const int force = force_s ? atoi(force_s) : 0;
@@ -713,7 +714,7 @@ extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, in
       const uint64_t b_reach = (sbk == 1 ? (uint64_t)(N + 64) * sbn : (uint64_t)K * sbk + N + 64) * 4;
       const bool dma_ok = p.avec && p.bvec && !(K & 31) && a_ext < (1ull << 31) && b_ext < (1ull << 31) && a_reach < 0xfffffff0ull &&
                           b_reach < 0xfffffff0ull;
-      static const bool dma_off = std::getenv("HMMC_NO_F32_DMA") != nullptr;      // A/B runs
+      const bool dma_off = hmmc_option(HMMC_OPT_NO_F32_DMA);                      // A/B runs
       int mi = 0;
       if (dma_ok && (force == 7 || force == 9)) mi = force == 7 ? 2 : 1;
       for (int c = 1; c <= 2 && dma_ok && !dma_off && !force; ++c) {
@@ -803,7 +804,7 @@ extern "C" int hmmc_eval_score(const float* queries_unit, const float* packed, f
   const long blocks = (long)((nq + TM - 1) / TM) * ((p.N + TN - 1) / TN);
   // the LDS-DMA kernel (same 64x64 tile and accumulator layout: 115-120 against 85-93 TFLOP/s at the VATEX size) where its
   // conditions hold: whole 32-deep K-steps, 32-bit byte offsets
-  static const bool dma_off = std::getenv("HMMC_NO_F32_DMA") != nullptr;
+  const bool dma_off = hmmc_option(HMMC_OPT_NO_F32_DMA);
   const uint64_t a_ext = (uint64_t)nq * E * 4, b_ext = (uint64_t)p.N * E * 4;
   if (!dma_off && !(E & 31) && a_ext + 64ull * E * 4 < (1ull << 31) && b_ext + 64ull * E * 4 < (1ull << 31)) {
     hipLaunchKernelGGL(gemm_f32_dma_topk_kernel, dim3((unsigned)blocks), dim3(256), 3 * (64 + 64) * 32 * 4, stream, p, (unsigned)a_ext,

@@ -9,7 +9,8 @@
 //   scratch : hmmc_tower_bwd_scratch_bytes() for the backward's transient gradients
 //   grads   : nlayers x 12 pointers, written (not accumulated)
 #include "common.h"
-#include <cstdlib>
+#include "options.h"
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -129,8 +130,7 @@ inline int wgrad(bool f32, const void* dy, const void* x, void* dw, int T, int N
 // ln1 / qkv addressed in place at stride L), and the attention runs for that query (hmmc_attention_f16_fwd_lead: bit-identical
 // class rows).  The Q columns of the other rows of qkv, the other rows of att and the other entries of stat are NOT written.
 inline bool lead_attention(bool lead, bool f32, int L) {
-  static const bool off = std::getenv("HMMC_NO_LEAD_ATTN") != nullptr;        // A/B runs: all queries in the last block, as before round 4
-  return lead && !f32 && L <= 256 && !off;
+  return lead && !f32 && L <= 256 && !hmmc_option(HMMC_OPT_NO_LEAD_ATTN);      // A/B runs: all queries in the last block, as before round 4
 }
 inline int lead_inproj_attention(const void* ln1, const void* w_in, const void* b_in, void* qkv, void* att, float* stat, long T, int nseq,
                                  int L, int heads, int D, int causal, hipStream_t s) {
@@ -488,6 +488,56 @@ WgradSync* wgrad_sync_for(hipStream_t s, hipStream_t sw) {
   return e;
 }
 }  // namespace
+
+// Give back the seven events of a (stream, weight-gradient stream) pair - for callers that create and destroy streams (a
+// handle value may be reused by a later stream; the pair's next hmmc_tower_bwd call simply creates a fresh set).  The caller
+// guarantees that no hmmc_tower_bwd work of the pair is still in flight (hipEventDestroy of a recorded, not yet completed
+// event is legal - the runtime defers the release - but a call enqueued concurrently from another thread would race).
+// stream == wgrad_stream == NULL releases every pair.  Returns the number of pairs released.
+extern "C" int hmmc_tower_release(hipStream_t stream, hipStream_t wgrad_stream) {
+  std::lock_guard<std::mutex> lk(g_sync_mu);
+  int n = 0;
+  for (auto it = g_sync.begin(); it != g_sync.end();) {
+    const bool all = !stream && !wgrad_stream;
+    if (all || (it->first.first == stream && it->first.second == wgrad_stream)) {
+      WgradSync* e = it->second;
+      if (e) {
+        if (e->ready) (void)hipEventDestroy(e->ready);
+        for (int k = 0; k < 4; ++k) if (e->done[k]) (void)hipEventDestroy(e->done[k]);
+        for (int k = 0; k < 2; ++k) if (e->gdone[k]) (void)hipEventDestroy(e->gdone[k]);
+        delete e;
+      }
+      it = g_sync.erase(it);
+      ++n;
+    } else {
+      ++it;
+    }
+  }
+  return n;
+}
+
+// The library's A/B switches (options.h).  key: "no_wgrad_group", "no_f32_wavek", "no_f32_dma", "no_lead_attn"; value 0 / 1.
+// hmmc_set_option returns HMMC_ERR_ARG for an unknown key; hmmc_get_option returns the value or HMMC_ERR_ARG.
+std::atomic<int> g_hmmc_options[HMMC_OPT_COUNT];
+namespace {
+int option_index(const char* key) {
+  static const char* const names[HMMC_OPT_COUNT] = {"no_wgrad_group", "no_f32_wavek", "no_f32_dma", "no_lead_attn"};
+  if (!key) return -1;
+  for (int i = 0; i < HMMC_OPT_COUNT; ++i)
+    if (std::strcmp(key, names[i]) == 0) return i;
+  return -1;
+}
+}  // namespace
+extern "C" int hmmc_set_option(const char* key, int value) {
+  const int i = option_index(key);
+  if (i < 0) return HMMC_ERR_ARG;
+  g_hmmc_options[i].store(value != 0, std::memory_order_relaxed);
+  return HMMC_OK;
+}
+extern "C" int hmmc_get_option(const char* key) {
+  const int i = option_index(key);
+  return i < 0 ? HMMC_ERR_ARG : g_hmmc_options[i].load(std::memory_order_relaxed);
+}
 
 // wgrad_stream (optional): the four weight-gradient GEMMs of every layer are leaves of the backward pass; given a second
 // stream they run there, beside the dgrad / LayerNorm / attention chain on `s`, and fill the CUs the persistent GEMMs of

@@ -176,8 +176,8 @@ def _ptr_array(tensors):
 # vs 1.18e-3 on text features, 1.217e-3 vs 1.218e-3 on frame features at true ViT-B/32 dims), but its fp16 errors are independent
 # of the reference's, so against the AS-WRITTEN goldens it sits at ~sqrt(2) x the regime gap.  The frame tower passes the 1.5 x
 # envelope of tests/test_gpu_model.py::test_envelope_at_true_vit_b32_dims that way; the text tower does not (text_feat max-abs
-# 1.85 x, rel-L2 1.34 x), so the default folds the frame tower only.  HMMC_FOLD_LN: "vit" (default), "all", "0" (never; the
-# training forward always runs the unfolded kernels).
+# 1.85 x, rel-L2 1.34 x), so the default folds the frame tower only.  HMMC_FOLD_LN: "vit" (default), "all", "0" (never).  This
+# switch governs the passes that keep no activations; the training forward has its own, HMMC_FOLD_LN_TRAIN below.
 _FOLD_LN = os.environ.get("HMMC_FOLD_LN", "vit")
 
 
@@ -191,8 +191,11 @@ def fold_train_enabled(tower_default, T, D, L):
     if _FOLD_LN_TRAIN in ("0", "", "off", False) or not (_FOLD_LN_TRAIN in ("all", "1", True) or tower_default):
         return False
     # the shapes hmmc_tower_fwd_fused(keep_acts = 1) takes: the grouped weight-gradient launch must exist for them
+    # (the library's own switch decides - hmmc_amd/_lib.py set it from HMMC_NO_WGRAD_GROUP when it loaded the library - so that
+    # Python and the library cannot read the variable differently)
+    from ._lib import get_option
     return (L <= 256 and D % 256 == 0 and T >= 2048 and (T + 256) * 4 * D * 2 < (1 << 31) - (1 << 24)
-            and not os.environ.get("HMMC_NO_WGRAD_GROUP"))
+            and not get_option("no_wgrad_group"))
 
 
 def fold_enabled(tower_default):
@@ -207,7 +210,7 @@ def fold_enabled(tower_default):
 def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep, lead_only=False, x_stat=None, fold=False):
     """Run all layers through the native layer runtime (hmmc_tower_fwd).  Returns (y, acts slab or None).
     lead_only: only token 0 of every sequence of y is defined (see include/hmmc_hip.h)."""
-    from ._lib import call, ptr, query
+    from ._lib import ERRORS, call, load, ptr, query, stream
     T, D = x.shape
     nl = len(params) // PER_LAYER
     slab = query("hmmc_tower_act_bytes", T, D, nseq, L, heads, int(fp32))
@@ -230,9 +233,16 @@ def _tower_forward(x, params, nseq, L, heads, causal, eps, fp32, keep, lead_only
         fwb = query("hmmc_tower_fold_bytes", T, D, nl, 1)
         fws = torch.empty(fwb, dtype=torch.uint8, device=x.device)
         y = torch.empty_like(x)
-        call("hmmc_tower_fwd_fused", ptr(x), ptr(x_stat), ptr(y), _ptr_array(params), ptr(acts), 1, nseq, L, heads, D, nl, int(causal),
-             float(eps), int(lead_only), last_exact, ptr(fws), fwb)
-        return y, (acts, fws, last_exact)
+        rc = getattr(load(), "hmmc_tower_fwd_fused")(ptr(x), ptr(x_stat), ptr(y), _ptr_array(params), ptr(acts), 1, nseq, L, heads, D, nl,
+                                                     int(causal), float(eps), int(lead_only), last_exact, ptr(fws), fwb, stream())
+        if rc == 0:
+            return y, (acts, fws, last_exact)
+        if rc != -2:
+            raise RuntimeError(f"hmmc_tower_fwd_fused failed: {ERRORS.get(rc, rc)}")
+        # HMMC_ERR_UNSUPPORTED (nothing was launched): a shape or setting the folded training runtime does not take after all -
+        # the unfolded kernels below compute the same function
+        del fws
+        acts = torch.empty(slab * nl, dtype=torch.uint8, device=x.device)
     wsb = query("hmmc_tower_workspace_bytes", T, D, nseq, int(fp32), 0)
     ws = ops.workspace(wsb, x.device, "tower")
     y = torch.empty_like(x)

@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -144,10 +145,22 @@ def clip_grad_norm_(parameters, max_norm):
         tbl.sumsq_after = torch.zeros_like(tbl.sumsq)
     call("hmmc_mt_clip_grad_norm_keep", ptr(tbl.tab), ptr(tbl.chunk), tbl.nchunks, ptr(tbl.sumsq), tbl.T, float(max_norm), ptr(out),
          ptr(tbl.sumsq_after))
+    # The gradients are named by tensor OBJECT (weak references), not by address: the library's raw-pointer kernels never bump
+    # `_version` and the caching allocator hands the same addresses back every step, so address + version alone would let a
+    # later, different gradient at the same place (clip, no step, zero_grad(set_to_none), backward, step without clip) pass.
     _pending_norms[str(dev)] = {"pids": np.fromiter((id(p) for p in plist), dtype=np.int64, count=n), "ptrs": rows[:, 1].copy(),
                                 "versions": np.fromiter((g._version for g in grads), dtype=np.int64, count=n),
+                                "grads": [weakref.ref(g) for g in grads],
                                 "norms": tbl.sumsq_after, "stream": torch.cuda.current_stream(dev)}
     return out[1]
+
+
+def _drop_pending_norms(device=None):
+    """Forget what the last clip_grad_norm_ left for the optimizer (a step that does not consume it, zero_grad)."""
+    if device is None:
+        _pending_norms.clear()
+    else:
+        _pending_norms.pop(str(device), None)
 
 
 class BertAdam(Optimizer):
@@ -256,7 +269,18 @@ class BertAdam(Optimizer):
         if not (np.array_equal(rec["ptrs"][host], grad_ptrs) and
                 np.array_equal(np.fromiter((g._version for g in grads), dtype=np.int64, count=len(grads)), rec["versions"][host])):
             return None                                        # another gradient tensor, or one written to after the clip
+        refs = rec["grads"]
+        if not all(refs[j]() is g for j, g in zip(host.tolist(), grads)):
+            return None                                        # a different tensor object at the same address (see clip_grad_norm_)
         return rec["norms"], cached[2]
+
+    def zero_grad(self, set_to_none: bool = True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.is_cuda:
+                    _drop_pending_norms(p.device)
+                    break
+        return super().zero_grad(set_to_none=set_to_none)
 
     def load_state_dict(self, state_dict):
         self._fast, self._table = None, None                  # the cached tables point at the old moment tensors
@@ -290,6 +314,7 @@ class BertAdam(Optimizer):
                 loss = closure()
         if self._fast_step():
             return loss
+        _drop_pending_norms()                               # the slow path forms its own norms: a hand-over is never left behind
         rows, frows, group_steps = [], {}, {}
         dev = None
         for gi, group in enumerate(self.param_groups):

@@ -9,10 +9,13 @@
  * workspaces are pre-allocated; hmmc_*_workspace() returns the bytes an op needs); kernels are
  * enqueued on `stream` (a hipStream_t) and never synchronise; no device memory is ever allocated.
  * Re-entrant across host threads and devices (device properties and LDS opt-ins are kept per
- * device).  Process-wide state, all of it listed here: (1) hmmc_gemm_reserve_cus(n), a setting;
- * (2) the benchmark timing switch hmmc_gemm_profile_start/stop (mutex-protected; creates HIP events
- * while on, and stop() synchronises the device); (3) five HIP events per (stream, weight-gradient
- * stream) pair, created by that pair's first hmmc_tower_bwd call and reused by every later one.
+ * device).  Process-wide state, all of it listed here: (1) hmmc_gemm_reserve_cus(n) and the A/B switches
+ * of hmmc_set_option, settings; (2) the benchmark timing switch hmmc_gemm_profile_start/stop
+ * (mutex-protected; creates HIP events while on, and stop() synchronises the device); (3) seven HIP
+ * events per (stream, weight-gradient stream) pair, created by that pair's first hmmc_tower_bwd /
+ * hmmc_tower_bwd_fold call, reused by every later one and given back by hmmc_tower_release.
+ * The library reads NO environment variable: results and speed depend on the arguments and on the
+ * settings above only.
  * Return value: 0 on success, HMMC_ERR_* (< 0) otherwise — nothing is launched on error.
  * fp16 buffers are IEEE binary16; "tokens" are rows of a row-major [tokens, D] matrix with each
  * sequence's L tokens contiguous.
@@ -383,6 +386,23 @@ int hmmc_tower_bwd_fold(const void* dy, void* dx, const void* x0, const void* co
 int hmmc_tower_bwd(const void* dy, void* dx, const void* x0, const void* const* params, void* const* grads, const void* acts,
                    void* scratch, int nseq, int L, int heads, int D, int nlayers, int causal, int fp32, int lead_only,
                    void* workspace, size_t ws_bytes, hmmc_stream_t wgrad_stream, hmmc_stream_t stream);
+
+/* Give back the seven events of the (stream, wgrad_stream) pair (process-wide state (3) of the header comment) - for callers
+ * that create and destroy streams.  No hmmc_tower_bwd work of the pair may still be in flight.  Both NULL: every pair.
+ * Returns the number of pairs released; the pair's next hmmc_tower_bwd call creates a fresh set. */
+int hmmc_tower_release(hmmc_stream_t stream, hmmc_stream_t wgrad_stream);
+
+/* A/B switches (process-wide, 0 / 1, all default 0), the only knobs besides hmmc_gemm_reserve_cus; the library itself reads
+ * no environment variable (hmmc_amd/_lib.py maps HMMC_NO_WGRAD_GROUP etc. onto these when it loads the library):
+ *   "no_wgrad_group"  one hmmc_gemm_f16 launch per weight gradient instead of hmmc_gemm_f16_wgrad_group (hmmc_tower_bwd;
+ *                     hmmc_gemm_f16_wgrad_group_workspace then returns 0 and hmmc_tower_fwd_fused(keep_acts = 1) is unsupported)
+ *   "no_f32_wavek"    hmmc_gemm_f32 never takes the wave-split-K kernel
+ *   "no_f32_dma"      hmmc_gemm_f32 / hmmc_eval_score never take the LDS-DMA kernel
+ *   "no_lead_attn"    a lead_only tower's last block runs its attention for every query
+ * Results are bit-identical either way for no_wgrad_group / no_lead_attn (class-token rows) and equal to fp32 summation order
+ * for the two fp32 switches.  hmmc_set_option: HMMC_ERR_ARG for an unknown key.  hmmc_get_option: the value, or HMMC_ERR_ARG. */
+int hmmc_set_option(const char* key, int value);
+int hmmc_get_option(const char* key);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,9 @@ def declared():
         ret, name, args = m.groups()
         codes = ""
         for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
-            if "*" in a or "hmmc_stream_t" in a:
+            if a.startswith("const char*"):
+                codes += "s"
+            elif "*" in a or "hmmc_stream_t" in a:
                 codes += "p"
             else:
                 codes += CODE[a.split()[-2] if len(a.split()) > 1 else a]
@@ -44,6 +46,38 @@ def test_ctypes_signatures_match_header():
     assert set(decl) == set(_lib.SIGNATURES), set(decl) ^ set(_lib.SIGNATURES)
     for name, sig in decl.items():
         assert _lib.SIGNATURES[name] == sig, (name, _lib.SIGNATURES[name], sig)
+
+
+def test_options_and_release_entry_points(monkeypatch):
+    """hmmc_set_option / hmmc_get_option / hmmc_tower_release (no GPU needed: settings and an empty event cache), and the
+    environment translation of hmmc_amd/_lib.py - the library itself reads no environment variable."""
+    from hmmc_amd import _lib
+    lib = _lib.load()
+    for key in _lib.ENV_OPTIONS.values():
+        before = _lib.get_option(key)
+        _lib.set_option(key, True)
+        assert _lib.get_option(key) is True
+        _lib.set_option(key, False)
+        assert _lib.get_option(key) is False
+        _lib.set_option(key, before)
+    assert lib.hmmc_set_option(b"no_such_option", 1) == -1 and lib.hmmc_get_option(b"no_such_option") == -1
+    assert lib.hmmc_set_option(None, 1) == -1
+    with pytest.raises(KeyError):
+        _lib.set_option("nope", 1)
+    assert lib.hmmc_tower_release(None, None) == 0           # nothing cached in a process that never ran a tower backward
+    # no getenv in the product sources (the scratch-only HMMC_F32_PICK sits behind #ifdef HMMC_SCRATCH)
+    import glob
+    for src in glob.glob(os.path.join(ROOT, "hmmc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "hmmc_amd", "csrc", "*.h")):
+        text = re.sub(r"#ifdef HMMC_SCRATCH.*?#e(lse|ndif)", "", open(src).read(), flags=re.S)
+        assert "getenv" not in text, src
+    # a variable that is present - even empty - switches its option on when the library is loaded
+    monkeypatch.setenv("HMMC_NO_F32_WAVEK", "")
+    monkeypatch.setattr(_lib, "_lib", None)
+    try:
+        _lib.load()
+        assert _lib.get_option("no_f32_wavek") is True
+    finally:
+        _lib.set_option("no_f32_wavek", False)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -20,19 +20,31 @@ KEYS = ["text_encoder.text_projection", "visual_encoder.visual.conv1.weight", "v
         "visual_encoder.temporal_transformer.resblocks.0.attn.in_proj_weight", "visual_encoder.frame_position_embeddings.weight"]
 
 
-def _run(rank, world, store, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    if world > 1:
-        dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
+def _init(rank, world, store, backend):
+    """Process group of `world` ranks; returns this rank's device index.  gloo: every rank on device 0 (what one GPU allows);
+    nccl (= RCCL): one device per rank, initialised BEFORE anything in this fresh process touches the GPU
+    (tests/test_gpu_rccl_multi.py, skipped below two devices)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = rank if backend == "nccl" else 0
+    if world > 1 or backend == "nccl":
+        kw = {"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}
+        dist.init_process_group(backend, init_method=f"file://{store}", rank=rank, world_size=world, **kw)
+    torch.cuda.set_device(dev)
+    if backend == "nccl" and world > 1:
+        from hmmc_amd import ops
+        ops.reserve_cus_for_collectives()          # 16 CUs out of every GEMM grid, as the towers do under world_size > 1
+    return dev
+
+
+def _run(rank, world, store, out_dir, backend="gloo", B=4):
+    dev = _init(rank, world, store, backend)
     from hmmc_amd.modeling import BirdModel
-    torch.cuda.set_device(0)
     model = BirdModel.from_pretrained("cross-base", state_dict=synth.finetune_state(synth.TINY),
                                       task_config=task_config(rank=rank)).cuda().train()
     for m in model.modules():                  # exercise the per-run autograd nodes the towers use under DDP
         if hasattr(m, "ddp_layers_per_node"):
             m.ddp_layers_per_node = 1
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0]) if world > 1 else model
-    B = 4
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev]) if world > 1 else model
     b = B // world
     ids, mask, vid, vf, idx = [t[rank * b:(rank + 1) * b].cuda() for t in synth.finetune_batch(B, 4, 32, tag="ddp")]
     loss = net(ids, mask, vid, vf, idx, 1)
@@ -40,8 +52,31 @@ def _run(rank, world, store, out_dir):
     torch.cuda.synchronize()
     P = dict(model.named_parameters())
     torch.save({"loss": loss.detach().cpu(), **{k: P[k].grad.float().cpu() for k in KEYS}}, os.path.join(out_dir, f"w{world}r{rank}.pt"))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+
+
+# Tolerances of the 2-rank = 1-process statement, MEASURED (round 5, printed by the test with -s): the two runs differ by fp16
+# rounding only - each rank's towers see half the rows, so tile paths and the order of the partial sums in every weight
+# gradient change.  Worst case over KEYS at the tiny dims: 1 - cos <= FT_COS, | norm ratio - 1 | <= FT_RATIO.  A slip in the
+# gather backward's scaling (x world, / world) moves the ratio by a factor of 2; a 2 % slip is 10 x the bound.
+FT_COS, FT_RATIO, FT_LOSS = 2e-4, 2e-3, 5e-4
+
+
+def check_finetune(ref, outs):
+    worst = {"cos": 0.0, "ratio": 0.0, "loss": 0.0}
+    for o in outs:
+        worst["loss"] = max(worst["loss"], abs(float(o["loss"]) - float(ref["loss"])))
+        for k in KEYS:
+            a, b = o[k].flatten().double(), ref[k].flatten().double()
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+            ratio = float(a.norm() / (b.norm() + 1e-30))
+            worst["cos"], worst["ratio"] = max(worst["cos"], 1 - cos), max(worst["ratio"], abs(ratio - 1))
+            assert 1 - cos < FT_COS and abs(ratio - 1) < FT_RATIO, (k, 1 - cos, ratio)
+    print("2 ranks vs 1 process (fine-tune):", worst)
+    assert worst["loss"] < FT_LOSS, worst
+    for k in KEYS:      # DDP left identical gradients on every rank
+        assert all(torch.equal(outs[0][k], o[k]) for o in outs[1:]), k
 
 
 def test_two_ranks_equal_single_process():
@@ -50,15 +85,7 @@ def test_two_ranks_equal_single_process():
         mp.spawn(_run, args=(2, os.path.join(d, "s2"), d), nprocs=2, join=True)
         ref = torch.load(os.path.join(d, "w1r0.pt"))
         outs = [torch.load(os.path.join(d, f"w2r{r}.pt")) for r in range(2)]
-    for o in outs:
-        assert abs(float(o["loss"]) - float(ref["loss"])) < 2e-3, (float(o["loss"]), float(ref["loss"]))
-        for k in KEYS:
-            a, b = o[k].flatten(), ref[k].flatten()
-            cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-20))
-            ratio = float(a.norm() / (b.norm() + 1e-20))
-            assert cos > 0.995 and abs(ratio - 1) < 0.03, (k, cos, ratio)
-    for k in KEYS:      # DDP left identical gradients on both ranks
-        assert torch.equal(outs[0][k], outs[1][k]), k
+    check_finetune(ref, outs)
 
 
 # ----------------------------------------------------------------------------- pre-training, two ranks
@@ -73,20 +100,17 @@ PT_BUFFERS = ["queue_v_cross_ng", "queue_title_cross_ng", "queue_tag_cross_ng", 
               "visual_encoder_k.visual.proj", "text_encoder_k.ln_final.weight"]
 
 
-def _run_pretrain(rank, world, store, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    if world > 1:
-        dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
+def _run_pretrain(rank, world, store, out_dir, backend="gloo"):
+    dev = _init(rank, world, store, backend)
     from conftest import golden
     from hmmc_amd.modeling import BirdPreTrainedModel
-    torch.cuda.set_device(0)
     g = golden("moco_aswritten")
     K, B, Fr = int(g["K"]), int(g["B"]), int(g["F"])
     cfg = task_config(rank=rank, contrast_num_negative=K, max_frames=Fr, dataset="chvtt")
     model = BirdPreTrainedModel.from_pretrained("cross-base", state_dict=synth.pretrain_state(synth.TINY, K, Fr),
                                                 task_config=cfg).cuda().train()
     # t_projector is built, EMA'd and never used (reference modules/modeling.py:113-114): find_unused_parameters as main_pretrain.py:204
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True) if world > 1 else model
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev], find_unused_parameters=True) if world > 1 else model
     b = B // world
     sl = slice(rank * b, (rank + 1) * b)
     batch = synth.pretrain_batch(B, Fr, tag="moco.s0")
@@ -102,7 +126,7 @@ def _run_pretrain(rank, world, store, out_dir):
     out.update({k: P[k].grad.float().cpu() for k in PT_KEYS})
     out.update({k: S[k].float().cpu() for k in PT_BUFFERS})
     torch.save(out, os.path.join(out_dir, f"p{world}r{rank}.pt"))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -116,6 +140,10 @@ def test_pretrain_two_ranks_equal_single_process():
         mp.spawn(_run_pretrain, args=(2, os.path.join(d, "s2"), d), nprocs=2, join=True)
         ref = torch.load(os.path.join(d, "p1r0.pt"))
         outs = [torch.load(os.path.join(d, f"p2r{r}.pt")) for r in range(2)]
+    check_pretrain(ref, outs)
+
+
+def check_pretrain(ref, outs):
     # FAM / VTM / FTM are means over a rank's rows: their average over the (equal-sized) ranks is the global mean
     for i, nm in enumerate(("FAM", "VTM", "FTM")):
         avg = 0.5 * (outs[0]["parts"][i] + outs[1]["parts"][i])
@@ -192,16 +220,14 @@ def test_rccl_one_rank_ddp_is_bit_identical():
 
 # ----------------------------------------------------------------------------- several optimizer steps under DDP
 
-def _run_steps(rank, world, store, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
+def _run_steps(rank, world, store, out_dir, backend="gloo"):
+    dev = _init(rank, world, store, backend)
     from hmmc_amd.modeling import BirdModel
     from hmmc_amd.optimization import clip_grad_norm_
     from test_gpu_model import prep_optimizer
-    torch.cuda.set_device(0)
     cfg = task_config(rank=rank)
     model = BirdModel.from_pretrained("cross-base", state_dict=synth.finetune_state(synth.TINY), task_config=cfg).cuda().train()
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True)     # as bench.py
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev], gradient_as_bucket_view=True)     # as bench.py
     opt = prep_optimizer(model, cfg, 20)
     params = [p for p in model.parameters() if p.requires_grad]
     B = 8

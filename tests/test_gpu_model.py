@@ -815,6 +815,55 @@ def test_optimizer_takes_the_norms_the_clip_left_bit_identical(max_norm, scales)
     assert all(torch.equal(a, b) for a, b in zip(ref, got_s)), "step on another stream"
 
 
+def _clip_skip_then_step(shared, via_optimizer_zero_grad):
+    """clip, NO step (a skipped iteration), gradients dropped, new gradients (other values, version 0 again, and - the caching
+    allocator being what it is - at the old addresses), step WITHOUT a clip."""
+    from hmmc_amd import optimization
+    from hmmc_amd.optimization import BertAdam, clip_grad_norm_
+    g = torch.Generator().manual_seed(21)
+    sizes = [(40000, torch.float16), (77, torch.float32), (32768, torch.float16), (100003, torch.float32)]
+    ps = [torch.nn.Parameter((torch.randn(n, generator=g) * 0.1).to(dt).to(DEV)) for n, dt in sizes]
+    opt = BertAdam(ps, lr=1e-3, warmup=0.1, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6, t_total=50, max_grad_norm=1.0)
+    old = optimization._NO_SHARED_NORMS
+    optimization._NO_SHARED_NORMS = not shared
+    reused = 0
+    try:
+        for step in range(2):                                   # the first step plans the fast path
+            for p in ps:
+                p.grad = (torch.randn(p.shape, generator=g) * 2.0).to(p.dtype).to(DEV)
+            clip_grad_norm_(ps, 1.0)
+            opt.step()
+        for p in ps:
+            p.grad = (torch.randn(p.shape, generator=g) * 5.0).to(p.dtype).to(DEV)
+        clip_grad_norm_(ps, 1.0)                                # leaves norms for a step() that never comes
+        addrs = [p.grad.data_ptr() for p in ps]
+        if via_optimizer_zero_grad:
+            opt.zero_grad()
+        else:
+            for p in ps:
+                p.grad = None
+        for p in ps:                                            # in reverse size order the allocator hands each block back
+            p.grad = (torch.randn(p.shape, generator=g) * 0.3).to(p.dtype).to(DEV)
+        reused = sum(int(p.grad.data_ptr() == a and p.grad._version == 0) for p, a in zip(ps, addrs))
+        opt.step()
+    finally:
+        optimization._NO_SHARED_NORMS = old
+    torch.cuda.synchronize()
+    return [t.detach().clone() for p in ps for t in (p, p.grad, opt.state[p]["next_m"], opt.state[p]["next_v"])], reused
+
+
+@pytest.mark.parametrize("via_optimizer_zero_grad", [False, True])
+def test_stale_clip_norms_are_not_taken_by_a_later_step(via_optimizer_zero_grad):
+    """Advisor, round 4: the hand-over of per-tensor norms from `clip_grad_norm_` to `BertAdam.step()` was keyed on gradient
+    address and version counter; the library's raw-pointer kernels never bump a version and the allocator returns the same
+    addresses, so `clip; (no step); zero_grad(set_to_none); backward; step` passed both checks with the PREVIOUS gradients'
+    norms.  The record now names the gradient tensors themselves (weak references) and is dropped by `zero_grad()` and by the
+    slow path of `step()`."""
+    ref, _ = _clip_skip_then_step(False, via_optimizer_zero_grad)
+    got, reused = _clip_skip_then_step(True, via_optimizer_zero_grad)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got)), f"stale norms were used ({reused} gradient addresses were reused)"
+
+
 @pytest.mark.parametrize("width,heads,L,nseq,causal", [(256, 4, 50, 48, False), (512, 8, 32, 80, True)])
 def test_tower_grouped_weight_gradients_streams_and_oracle(width, heads, L, nseq, causal):
     """A tower backward with enough tokens (>= 2048) and 256-multiple widths takes the grouped weight-gradient launch
