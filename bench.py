@@ -8,6 +8,7 @@ main_pretrain.py:213-245) on synthetic batches.  Default = BASELINE.json's headl
     python bench.py --mode pretrain --batch 128                       # SURVEY config 4 (FAM+VTM+FTM+MLM, MoCo K=1024)
     python bench.py --mode eval --frames 24                           # eval leg at VATEX size: 15 000 x 1 500 x 24
     python bench.py --clip ViT-B/16 --frames 24 --batch 16            # one rank's share of SURVEY config 5
+    python bench.py --regime fp32                                     # the reference's model.float() recipe: the regime held to 1e-3
     python bench.py --gpus N --steps K --warmup W                     # starts its own N ranks (children, torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -29,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0           # dense fp16/bf16, MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.0        # exact-f32 MFMA (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md
 
 
 def flop_model(dims, frames, text_len):
@@ -436,6 +438,14 @@ def main():
     ap.add_argument("--tag-length", type=int, default=25)
     ap.add_argument("--negatives", type=int, default=1024, help="MoCo queue length K (pretrain)")
     ap.add_argument("--clip", default="ViT-B/32")
+    ap.add_argument("--regime", choices=("f16", "fp32"), default="f16",
+                    help="f16: the towers as the reference builds them (convert_weights: fp16 weights and activations); fp32: after "
+                         "model.float() + text_encoder.dtype = float32, the reference's own fp32-upcast recipe "
+                         "(modules/module_clip.py:566-577) - every stage in exact fp32, the regime whose logits are held to 1e-3 "
+                         "(tests/test_gpu_fp32_regime.py); roofline against the 157 TFLOP/s exact-f32 MFMA peak")
+    ap.add_argument("--unfolded-steps", type=int, default=3,
+                    help="fine-tune / pre-train, f16 regime: extra timed steps with HMMC_FOLD_LN=0 HMMC_FOLD_LN_TRAIN=0 - the kernels "
+                         "whose rounding points are the reference's - reported as ms_per_step_unfolded (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
                     help="run everything on one stream (no tower / weight-gradient overlap): the mode whose rocprofv3 "
@@ -509,6 +519,12 @@ def main():
     torch.manual_seed(42)
     cls = BirdPreTrainedModel if pretrain else BirdModel
     model = cls.from_pretrained("cross-base", state_dict=None, task_config=cfg).to(dev).train()
+    fp32 = args.regime == "fp32"
+    if fp32:
+        model.float()                                    # CLIP(...).float() of the reference (modules/module_clip.py:566-577) ...
+        model.text_encoder.dtype = torch.float32         # ... and the stored dtype attribute the text path casts to (module_cross.py:256)
+        if pretrain:
+            model.text_encoder_k.dtype = torch.float32
     optimizer = prep_optimizer(model, cfg, t_total=1000)
     net = model
     if world > 1:
@@ -556,13 +572,36 @@ def main():
     final_loss = float(loss.detach())
     ops.raise_on_device_errors()
 
+    import hmmc_amd.functional as _fn
+    import hmmc_amd.modeling as _md
+    # The same step on the unfolded kernels (HMMC_FOLD_LN=0 HMMC_FOLD_LN_TRAIN=0: LayerNorm then GEMM, every rounding point where
+    # the reference has it) - the default folds ln_1 / ln_2 of the frame tower into in_proj / c_fc.
+    ms_unfolded = None
+    if args.unfolded_steps > 0 and not fp32:
+        pol = (_fn._FOLD_LN, _fn._FOLD_LN_TRAIN)
+        _fn._FOLD_LN, _fn._FOLD_LN_TRAIN = "0", "0"
+        step(args.warmup + args.steps)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        for i in range(args.unfolded_steps):
+            step(args.warmup + args.steps + 1 + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tun = torch.tensor([time.perf_counter() - tu], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tun, op=dist.ReduceOp.MAX)
+        ms_unfolded = float(tun.item()) / args.unfolded_steps * 1e3
+        _fn._FOLD_LN, _fn._FOLD_LN_TRAIN = pol
+        step(args.warmup + args.steps)                   # back on the default kernels (workspaces, allocator state)
+
     # Roofline of the dominant kernel.  The timed region above runs the text tower, the frame tower and the weight
     # gradients on three streams, so a launch's HIP events there also bracket the time it waits for CUs held by another
     # stream's kernels.  The per-launch durations are therefore taken over `--roofline-steps` further steps of the same
     # loop with the overlap switched off (one stream; this is also what rocprofv3 --kernel-trace sees, it serialises
     # dispatches), events recorded on the launch stream around every hmmc_gemm_f16 call.
-    import hmmc_amd.functional as _fn
-    import hmmc_amd.modeling as _md
     ov = (_md._OVERLAP_TOWERS, _fn._WGRAD_STREAM)
     # The text tower's AccumulateGrad nodes were created under the side stream; as long as the last graph (`loss`) lives they are
     # reused, and torch warns ("AccumulateGrad node's stream does not match") when the single-stream steps below produce their
@@ -590,7 +629,7 @@ def main():
     # eval mode, timed with events on the current stream; FLOPs in the reference's formulation (all-token final projection)
     fm = flop_model(dims, args.frames, args.length)
     vit_forward = None
-    if args.vit_forward_iters > 0:
+    if args.vit_forward_iters > 0 and not fp32:
         frames_flat = video.view(b * args.frames, 3, res, res)
         enc = model.visual_encoder
 
@@ -624,14 +663,20 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = args.batch * args.steps / dt
+        # the dominant kernel family: the fp16 GEMM (three operand layouts) as built, the exact-fp32 GEMM in the fp32 regime
+        f32_prof = prof.pop("f32", None)
+        if fp32:
+            prof = {"f32": f32_prof} if f32_prof else {}
+        peak = MFMA_F32_PEAK_TFLOPS if fp32 else MFMA_PEAK_TFLOPS
         flops = sum(p["flops"] for p in prof.values())
         secs = sum(p["seconds"] for p in prof.values())
         launches = sum(p["launches"] for p in prof.values())
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         lps = launches // max(args.roofline_steps, 1)
-        roof = {"bound": "mfma", "kernel": "gemm_f16_kernel (fp16 MFMA GEMM, all operand layouts)",
-                "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None, "traffic_unit": "bytes/launch",
+        roof = {"bound": "mfma", "kernel": ("gemm_f32_*kernel (exact-f32 MFMA 16x16x4 GEMM, all orientations and tile kernels)" if fp32 else
+                                            "gemm_f16_kernel (fp16 MFMA GEMM, all operand layouts)"),
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None, "traffic_unit": "bytes/launch",
                 "launches_per_step": lps,
                 "avg_launch_us": round(secs / max(launches, 1) * 1e6, 2),
                 "measured_over": f"{args.roofline_steps} single-stream steps after the timed region "
@@ -640,30 +685,45 @@ def main():
                 "algorithmic_bytes_per_launch": round(sum(p.get("bytes", 0) for p in prof.values()) / max(launches, 1)) or None,
                 "by_layout": {k: {"tflops": round(p["flops"] / p["seconds"] / 1e12, 1), "launches": p["launches"],
                                   "avg_us": round(p["seconds"] / p["launches"] * 1e6, 2)} for k, p in prof.items()}}
-        roof["traffic"], roof["traffic_source"] = recorded_traffic(args, b, lps)
+        if fp32:
+            roof["traffic_source"] = "not collected for the fp32 regime"
+        else:
+            roof["traffic"], roof["traffic_source"] = recorded_traffic(args, b, lps)
+            if f32_prof:
+                roof["gemm_f32_beside_it"] = {"tflops": round(f32_prof["flops"] / f32_prof["seconds"] / 1e12, 1), "launches": f32_prof["launches"] // max(args.roofline_steps, 1),
+                                              "ms_per_step": round(f32_prof["seconds"] / max(args.roofline_steps, 1) * 1e3, 3),
+                                              "note": "hmmc_gemm_f32 launches of the same steps (temporal transformer, heads): exact-f32 MFMA, peak 157"}
         if pretrain:
             c4 = (args.clip == "ViT-B/32" and args.frames == 12 and args.title_length == 45 and args.tag_length == 25)
             per_pair, per_pair_exec = (FLOP_PER_PAIR_PRETRAIN_C4 if c4 else None), None
             workload = (f"{args.clip} CHVTT-shaped pre-train step (FAM+VTM+FTM+MLM, MoCo m=0.99 K={args.negatives}), global B={args.batch} "
                         f"F={args.frames} title L={args.title_length} tag L={args.tag_length}, {res}x{res}, fwd+bwd+clip+BertAdam, random-init weights")
         else:
-            per_pair, per_pair_exec = fm["pair_train"], fm["pair_train_executed"]
+            # (the fp32 tower has no class-token pruning of the last block: it executes the reference's formulation)
+            per_pair, per_pair_exec = fm["pair_train"], (fm["pair_train"] if fp32 else fm["pair_train_executed"])
             workload = (f"{args.clip} english fine-tune step, global B={args.batch} F={args.frames} L_text={args.length}, "
                         f"{res}x{res}, fwd+bwd+clip+BertAdam, random-init weights")
-        headline = (not pretrain and args.batch == 256 and args.frames == 12 and args.clip == "ViT-B/32" and res == 224)
+        headline = (not pretrain and not fp32 and args.batch == 256 and args.frames == 12 and args.clip == "ViT-B/32" and res == 224)
         metric = ("video-text pairs/sec (whole node), B=256 F=12 224^2" if headline else
-                  f"video-text pairs/sec (whole node), {args.mode} {args.clip} B={args.batch} F={args.frames} {res}^2")
+                  f"video-text pairs/sec (whole node), {args.mode} {args.clip} B={args.batch} F={args.frames} {res}^2"
+                  + (", fp32 regime (model.float())" if fp32 else ""))
+        if fp32:
+            workload += "; fp32 regime: model.float() + text_encoder.dtype = float32 (the reference's fp32-upcast recipe), every stage exact fp32"
         out = {"metric": metric, "value": round(value, 2),
                "unit": "video-text pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-               "dtype": "f16", "data": "synthetic",
+               "dtype": "f32" if fp32 else "f16", "data": "synthetic",
                "config": {"workload": workload, "mode": args.mode, "global_batch": args.batch, "per_gpu_batch": b, "frames": args.frames,
                           "parallelism": f"dp{world}", "streams": "single" if args.single_stream else "overlapped",
                           "gemm_reserved_cus": reserved},
                "gflop_per_pair_reference_formulation": round(per_pair / 1e9, 2) if per_pair else None,
                "step_tflops": round(value * per_pair_exec / 1e12, 1) if per_pair_exec else None,
                "step_tflops_reference_formulation": round(value * per_pair / 1e12, 1) if per_pair else None,
-               "mfma_frac_whole_step": round(value * (per_pair_exec or per_pair) / 1e12 / (world * MFMA_PEAK_TFLOPS), 4) if per_pair else None,
+               "mfma_frac_whole_step": round(value * (per_pair_exec or per_pair) / 1e12 / (world * peak), 4) if per_pair else None,
+               "ms_per_step_unfolded": round(ms_unfolded, 2) if ms_unfolded else None,
+               "ms_per_step_unfolded_note": (f"{args.unfolded_steps} further steps of the same loop with HMMC_FOLD_LN=0 HMMC_FOLD_LN_TRAIN=0: LayerNorm "
+                                             "then GEMM with the reference's rounding points everywhere; `value` / `ms_per_step` are the default "
+                                             "(frame tower's ln_1 / ln_2 folded into in_proj / c_fc)") if ms_unfolded else None,
                "final_loss": round(final_loss, 4), "roofline": roof, "roofline_hbm": hbm, "comm": comm, "vit_forward": vit_forward,
                "peak_device_memory_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
         if world == 1 and not args.no_cpu_baseline:

@@ -1034,6 +1034,24 @@ std::mutex g_prof_mu;                 // hmmc_gemm_f16 may be called from severa
 std::vector<GemmProfRec> g_prof;
 }  // namespace
 
+// launch sites of other translation units (gemm_f32.hip): see options.h
+long hmmc_prof_begin(double flops, double bytes, int slot, hipStream_t stream) {
+  if (!g_prof_on) return -1;
+  GemmProfRec rec{};
+  if (hipEventCreate(&rec.e0) != hipSuccess) return -1;
+  if (hipEventCreate(&rec.e1) != hipSuccess) { (void)hipEventDestroy(rec.e0); return -1; }
+  rec.flops = flops; rec.bytes = bytes; rec.layout = slot;
+  (void)hipEventRecord(rec.e0, stream);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back(rec);
+  return (long)g_prof.size() - 1;
+}
+void hmmc_prof_end(long token, hipStream_t stream) {
+  if (token < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (token < (long)g_prof.size()) (void)hipEventRecord(g_prof[token].e1, stream);
+}
+
 extern "C" int hmmc_gemm_profile_start(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -1042,17 +1060,18 @@ extern "C" int hmmc_gemm_profile_start(void) {
   return HMMC_OK;
 }
 
-// out arrays of 3: layout 0 = forward (k-major x k-major), 1 = dgrad (k-major x m-major), 2 = wgrad (m-major A)
-// bytes = algorithmic operand bytes (A + B + C and the epilogue's bias / residual / aux tensors, each touched once)
+// out arrays of 4: slot 0 = forward (k-major x k-major), 1 = dgrad (k-major x m-major), 2 = wgrad (m-major A) of hmmc_gemm_f16,
+// 3 = hmmc_gemm_f32 (every orientation).  bytes = algorithmic operand bytes (A + B + C and the epilogue's bias / residual / aux
+// tensors, each touched once)
 extern "C" int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seconds, long* launches) {
   g_prof_on = false;
   if (!flops || !bytes || !seconds || !launches) return HMMC_ERR_ARG;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (int i = 0; i < 3; ++i) { flops[i] = 0; bytes[i] = 0; seconds[i] = 0; launches[i] = 0; }
+  for (int i = 0; i < 4; ++i) { flops[i] = 0; bytes[i] = 0; seconds[i] = 0; launches[i] = 0; }
   if (hipDeviceSynchronize() != hipSuccess) return HMMC_ERR_LAUNCH;
   for (auto& r : g_prof) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+    if (r.layout >= 0 && r.layout < 4 && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
       flops[r.layout] += r.flops; bytes[r.layout] += r.bytes; seconds[r.layout] += ms * 1e-3; launches[r.layout] += 1;
     }
     (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);

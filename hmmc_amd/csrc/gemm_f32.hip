@@ -647,9 +647,25 @@ void launch_f32(int bmode, dim3 grid, hipStream_t stream, const G32& p) {
 
 }  // namespace
 
+static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk,
+                         long sbn, int ldc, float alpha, const float* bias, const float* resid, float* aux_out,
+                         const float* aux_in, int epilogue, hipStream_t stream);
+
 extern "C" int hmmc_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk,
                              long sbn, int ldc, float alpha, const float* bias, const float* resid, float* aux_out,
                              const float* aux_in, int epilogue, hipStream_t stream) {
+  // bench.py's live timing (off unless hmmc_gemm_profile_start was called): slot 3 of hmmc_gemm_profile_stop
+  const double mn = (double)M * N;
+  const long tok = hmmc_prof_begin(2.0 * mn * K, 4.0 * ((double)M * K + (double)N * K + mn) + ((epilogue & EPI_BIAS) ? 4.0 * N : 0.0) +
+                                   4.0 * mn * (((epilogue & EPI_RESID) ? 1 : 0) + ((epilogue & EPI_DGELU) ? 1 : 0) + (aux_out ? 1 : 0)), 3, stream);
+  const int rc = gemm_f32_impl(A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, alpha, bias, resid, aux_out, aux_in, epilogue, stream);
+  hmmc_prof_end(tok, stream);
+  return rc;
+}
+
+static int gemm_f32_impl(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk,
+                         long sbn, int ldc, float alpha, const float* bias, const float* resid, float* aux_out,
+                         const float* aux_in, int epilogue, hipStream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return HMMC_ERR_ARG;
   if ((sak != 1 && sam != 1) || (sbk != 1 && sbn != 1)) return HMMC_ERR_UNSUPPORTED;
   long a_ld = sak == 1 ? sam : sak, b_ld = sbk == 1 ? sbn : sbk;

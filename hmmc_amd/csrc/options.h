@@ -13,3 +13,9 @@ enum HmmcOption {
 };
 extern std::atomic<int> g_hmmc_options[HMMC_OPT_COUNT];
 static inline bool hmmc_option(HmmcOption o) { return g_hmmc_options[o].load(std::memory_order_relaxed) != 0; }
+
+// Live timing of GEMM launches for bench.py (hmmc_gemm_profile_start / _stop, gemm_f16.hip): a launch site brackets its kernels
+// with hmmc_prof_begin / hmmc_prof_end; slot 0-2 = the fp16 GEMM by operand layout, 3 = the exact-fp32 GEMM.  begin returns a
+// token (< 0: timing is off, end is a no-op).
+long hmmc_prof_begin(double flops, double bytes, int slot, hipStream_t stream);
+void hmmc_prof_end(long token, hipStream_t stream);

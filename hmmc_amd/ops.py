@@ -36,20 +36,20 @@ def reserve_cus_for_collectives():
 
 
 def gemm_profile_start():
-    """bench.py: time every hmmc_gemm_f16 launch (also those issued by the native tower runtime) with HIP events
-    recorded on the launch stream."""
+    """bench.py: time every hmmc_gemm_f16 / hmmc_gemm_f32 launch (also those issued by the native tower runtime) with HIP
+    events recorded on the launch stream."""
     _lib.load().hmmc_gemm_profile_start()
 
 
 def gemm_profile_stop():
     """-> {layout: {"flops", "bytes", "seconds", "launches"}} (synchronises)."""
     import ctypes
-    flops, nbytes, secs, n = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_long * 3)()
+    flops, nbytes, secs, n = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_long * 4)()
     rc = _lib.load().hmmc_gemm_profile_stop(flops, nbytes, secs, n)
     if rc:
         raise RuntimeError(f"hmmc_gemm_profile_stop failed: {rc}")
-    names = ("fwd_kk", "dgrad_km", "wgrad_mm")
-    return {names[i]: {"flops": flops[i], "bytes": nbytes[i], "seconds": secs[i], "launches": n[i]} for i in range(3) if n[i]}
+    names = ("fwd_kk", "dgrad_km", "wgrad_mm", "f32")             # three operand layouts of hmmc_gemm_f16; hmmc_gemm_f32
+    return {names[i]: {"flops": flops[i], "bytes": nbytes[i], "seconds": secs[i], "launches": n[i]} for i in range(4) if n[i]}
 
 
 def workspace(nbytes, device, tag="default"):

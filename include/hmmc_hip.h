@@ -63,8 +63,9 @@ size_t hmmc_gemm_f16_workspace(int M, int N, int K);
  * rows; hmmc_colsum over them gives the bias gradient of the layer that produced C's pre-image (c_fc at
  * module_clip.py:240) without re-reading C. */
 size_t hmmc_gemm_f16_colsum_rows(int M, int N, int K);
-/* Benchmark-only live timing of every hmmc_gemm_f16 launch with HIP events on the launch stream; stop() synchronises and
- * returns, per operand layout (0 forward, 1 dgrad, 2 wgrad), the summed 2MNK flops, algorithmic operand bytes, seconds and launch counts. */
+/* Benchmark-only live timing of every hmmc_gemm_f16 / hmmc_gemm_f32 launch with HIP events on the launch stream; stop()
+ * synchronises and returns in arrays of FOUR - slots 0 forward, 1 dgrad, 2 wgrad (hmmc_gemm_f16 by operand layout), 3 =
+ * hmmc_gemm_f32 - the summed 2MNK flops, algorithmic operand bytes, seconds and launch counts. */
 int hmmc_gemm_profile_start(void);
 int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seconds, long* launches);
 /* The weight gradients of one layer as ONE launch: dW_j[Np_j, Kp_j] = dY_j[T, Np_j]^T X_j[T, Kp_j], j < nprob <= 4, all over the

@@ -58,9 +58,10 @@ def _run(rank, world, store, out_dir, backend="gloo", B=4):
 
 # Tolerances of the 2-rank = 1-process statement, MEASURED (round 5, printed by the test with -s): the two runs differ by fp16
 # rounding only - each rank's towers see half the rows, so tile paths and the order of the partial sums in every weight
-# gradient change.  Worst case over KEYS at the tiny dims: 1 - cos <= FT_COS, | norm ratio - 1 | <= FT_RATIO.  A slip in the
-# gather backward's scaling (x world, / world) moves the ratio by a factor of 2; a 2 % slip is 10 x the bound.
-FT_COS, FT_RATIO, FT_LOSS = 2e-4, 2e-3, 5e-4
+# gradient change.  Measured worst case over KEYS at the tiny dims (gloo, 2 ranks on one MI355X): 1 - cos = 2.0e-7,
+# | norm ratio - 1 | = 2.0e-5, loss difference 0.0; the bounds below are 50 x / 10 x that.  A slip in the gather backward's
+# scaling (x world, / world) moves the ratio by a factor of 2; a 2 % slip is 100 x the bound.
+FT_COS, FT_RATIO, FT_LOSS = 1e-5, 2e-4, 1e-4
 
 
 def check_finetune(ref, outs):
@@ -72,9 +73,8 @@ def check_finetune(ref, outs):
             cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
             ratio = float(a.norm() / (b.norm() + 1e-30))
             worst["cos"], worst["ratio"] = max(worst["cos"], 1 - cos), max(worst["ratio"], abs(ratio - 1))
-            assert 1 - cos < FT_COS and abs(ratio - 1) < FT_RATIO, (k, 1 - cos, ratio)
     print("2 ranks vs 1 process (fine-tune):", worst)
-    assert worst["loss"] < FT_LOSS, worst
+    assert worst["cos"] < FT_COS and worst["ratio"] < FT_RATIO and worst["loss"] < FT_LOSS, worst
     for k in KEYS:      # DDP left identical gradients on every rank
         assert all(torch.equal(outs[0][k], o[k]) for o in outs[1:]), k
 
