@@ -400,8 +400,8 @@ int hmmc_tower_release(hmmc_stream_t stream, hmmc_stream_t wgrad_stream);
  *   "no_f32_wavek"    hmmc_gemm_f32 never takes the wave-split-K kernel
  *   "no_f32_dma"      hmmc_gemm_f32 / hmmc_eval_score never take the LDS-DMA kernel
  *   "no_lead_attn"    a lead_only tower's last block runs its attention for every query
- * Results are bit-identical either way for no_wgrad_group / no_lead_attn (class-token rows) and equal to fp32 summation order
- * for the two fp32 switches.  hmmc_set_option: HMMC_ERR_ARG for an unknown key.  hmmc_get_option: the value, or HMMC_ERR_ARG. */
+ * Results are bit-identical either way for no_lead_attn (class-token rows) and equal up to the order of the fp32 partial sums
+ * (the K split of a weight gradient, the tile kernel of an fp32 GEMM) for the other three.  hmmc_set_option: HMMC_ERR_ARG for an unknown key.  hmmc_get_option: the value, or HMMC_ERR_ARG. */
 int hmmc_set_option(const char* key, int value);
 int hmmc_get_option(const char* key);
 

@@ -257,7 +257,9 @@ def test_fold_grad_finish_against_the_definitions():
     torch.testing.assert_close(dbeta.double(), (W.double() * db.double()[:, None]).sum(0), rtol=1e-4, atol=1e-4)
 
 
-def _tower_and_reference(width, heads, L, nseq, layers, causal):
+def _tower_and_reference(width, heads, L, nseq, layers, causal, outlier=None, gscale=0.1):
+    """outlier = (every n-th row, factor): those rows of the input are multiplied by `factor` (large-variance tokens: rstd << 1);
+    gscale: size of the upstream gradient."""
     from hmmc_amd import module_clip
     torch.manual_seed(7)
     tw = module_clip.Transformer(width, layers, heads, attn_mask="causal" if causal else None)
@@ -268,8 +270,11 @@ def _tower_and_reference(width, heads, L, nseq, layers, causal):
         blk.ln_2.weight.data.add_(1.0)
     module_clip.convert_weights(tw)
     tw = tw.to(DEV)
-    x0 = (torch.randn(nseq * L, width) * 0.7 + 0.1).half().to(DEV)
-    wsel = torch.randn(nseq * L, width).to(DEV) * 0.1
+    x0 = torch.randn(nseq * L, width) * 0.7 + 0.1
+    if outlier is not None:
+        x0[::outlier[0]] *= outlier[1]
+    x0 = x0.half().to(DEV)
+    wsel = torch.randn(nseq * L, width).to(DEV) * gscale
 
     def fp32_run():
         P = [[q.detach().double().requires_grad_() for q in Fn.block_params(blk)] for blk in tw.resblocks]
@@ -324,6 +329,79 @@ def test_folded_training_tower_against_fp32_autograd(width, heads, L, nseq, laye
             worst.append((a1 / max(a0, 1e-4), f"layer {li} {nm}", a0, a1))
             assert a1 <= 2.0 * a0 + 3e-3, (li, nm, a1, a0)
     print("worst ratios:", sorted(worst, reverse=True)[:4])
+
+
+@pytest.mark.parametrize("factor,gscale", [(30.0, 1e-3), (100.0, 1e-4)])
+def test_folded_backward_with_large_variance_rows_and_small_gradients(factor, gscale, monkeypatch):
+    """Advisor, round 4: in the folded backward the data gradient in front of a LayerNorm is stored in fp16 ALREADY multiplied by
+    the row's rstd, and the c_fc bias gradient's column sums are rebuilt from those rounded values x 1 / rstd.  Rows with a large
+    variance (CLIP's outlier tokens: here every 16th row x 30 / x 100, rstd ~ 1/20 .. 1/70) push small gradients towards the fp16
+    subnormals.  The gradients that pass through that hand-over - c_fc bias and weight, ln_2 / ln_1 gamma and beta, in_proj - must
+    stay as close to fp64 autograd as the unfolded kernels' are (x 2 + 3e-3), whose own fp16 gradients are the reference's regime.
+    Measured (round 5): at x 30 / 1e-3 folded = unfolded on every tensor (7e-4 .. 1.1e-3 rel-L2 either way); at x 100 / 1e-4 the
+    tensors behind the scaled hand-over of the FOLDED layer (ln_1 / ln_2, in_proj / c_fc weight and bias) are 1.9 - 2.6 x further
+    from fp64 than unfolded (3.2e-3 against 1.2e-3): rstd ~ 1/70 times gradients that are fp16 subnormals already costs one to
+    two more bits there.  Inside the bound, recorded in DESIGN.md; `HMMC_FOLD_LN_TRAIN=0` is the exact path."""
+    width, heads, L, nseq, layers = 768, 12, 50, 64, 2
+    tw, x0, wsel, fp32_run = _tower_and_reference(width, heads, L, nseq, layers, False, outlier=(16, factor), gscale=gscale)
+    yr, dxr, gr = fp32_run()
+    monkeypatch.setattr(Fn, "_FOLD_LN_TRAIN", "vit")
+    res = {}
+    for fold in (False, True):
+        tw.fold_ln = fold
+        for prm in tw.parameters():
+            prm.grad = None
+        x = x0.clone().requires_grad_()
+        y = tw(x, nseq, L)
+        (y.float() * wsel).sum().backward()
+        res[fold] = (y.detach(), x.grad, [[q.grad for q in Fn.block_params(blk)] for blk in tw.resblocks])
+    assert not torch.equal(res[True][0], res[False][0]), "the folded kernels did not run"
+    names = ["ln_1.w", "ln_1.b", "in_proj.w", "in_proj.b", "out_proj.w", "out_proj.b", "ln_2.w", "ln_2.b", "c_fc.w", "c_fc.b", "c_proj.w", "c_proj.b"]
+    report, bad = [], []
+    e0, e1 = relerr(res[False][1], dxr), relerr(res[True][1], dxr)
+    report.append(("dx", e0, e1))
+    if e1 > 2.0 * e0 + 2e-3:
+        bad.append(("dx", e0, e1))
+    for li in range(layers):
+        for j, nm in enumerate(names):
+            a0, a1 = relerr(res[False][2][li][j], gr[li][j]), relerr(res[True][2][li][j], gr[li][j])
+            report.append((f"layer {li} {nm}", a0, a1))
+            if a1 > 2.0 * a0 + 3e-3:
+                bad.append((f"layer {li} {nm}", a0, a1))
+    print(f"outlier rows x {factor}, upstream gradient {gscale}: (tensor, unfolded rel-L2 vs fp64, folded)")
+    for r in report:
+        print("   %-22s %.3e %.3e" % r)
+    assert not bad, bad
+
+
+def test_unsupported_fused_training_forward_falls_back_to_the_unfolded_kernels(monkeypatch):
+    """Advisor, round 4: when hmmc_tower_fwd_fused(keep_acts = 1) answers HMMC_ERR_UNSUPPORTED (here: the grouped weight-gradient
+    launch switched off through hmmc_set_option AFTER Python decided to fold) training must fall back to the unfolded kernels -
+    same function, the reference's rounding points - instead of raising."""
+    from hmmc_amd import _lib
+    width, heads, L, nseq, layers = 256, 4, 10, 210, 2
+    tw, x0, wsel, _ = _tower_and_reference(width, heads, L, nseq, layers, False)
+    monkeypatch.setattr(Fn, "_FOLD_LN_TRAIN", "vit")
+    _lib.set_option("no_wgrad_group", True)                                       # the library cannot run the folded training forward ...
+    try:
+        tw.fold_ln = False
+        assert not Fn.fold_train_enabled(True, nseq * L, width, L)                # (and Python, asking the library, knows)
+        x = x0.clone().requires_grad_()
+        y0 = tw(x, nseq, L)
+        (y0.float() * wsel).sum().backward()
+        ref = (y0.detach().clone(), x.grad.clone(), [q.grad.clone() for blk in tw.resblocks for q in Fn.block_params(blk)])
+        for prm in tw.parameters():
+            prm.grad = None
+        tw.fold_ln = True
+        monkeypatch.setattr(Fn, "fold_train_enabled", lambda *a, **k: True)       # ... while Python says "fold"
+        x = x0.clone().requires_grad_()
+        y1 = tw(x, nseq, L)
+        (y1.float() * wsel).sum().backward()
+    finally:
+        _lib.set_option("no_wgrad_group", False)
+    got = (y1.detach(), x.grad, [q.grad for blk in tw.resblocks for q in Fn.block_params(blk)])
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    assert all(torch.equal(a, b) for a, b in zip(ref[2], got[2]))
 
 
 def test_folded_training_tower_is_deterministic_and_chunks_agree(monkeypatch):
