@@ -52,6 +52,7 @@ SIGNATURES = {
     "hmmc_vit_embed": ("pppliiip", "i"),
     "hmmc_text_embed": ("ppppliilpip", "i"),
     "hmmc_text_embed_bwd": ("ppplilip", "i"),
+    "hmmc_eot_index": ("ppiillp", "i"),
     "hmmc_cast": ("pplip", "i"),
     "hmmc_attention_f16_fwd": ("pppiiiip", "i"),
     "hmmc_attention_f16_bwd": ("ppppppiiiip", "i"),

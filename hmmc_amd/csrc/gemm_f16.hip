@@ -1237,7 +1237,9 @@ GroupPlan group_plan(const int* Np, const int* Kp, int nprob, int T) {
 }
 bool group_ok(const int* Np, const int* Kp, int nprob, int T) {
   if (hmmc_option(HMMC_OPT_NO_WGRAD_GROUP)) return false;       // A/B runs: one launch per gradient, as before round 3
-  if (!Np || !Kp || nprob < 1 || nprob > GROUP_MAX || T < 2048) return false;
+  // (at least 8 K-tiles: group_plan keeps >= 4 per item.  Round 5 lowered this from 2048 tokens: the text tower at 32 captions per
+  // GPU - 1 024 tokens - ran 4 launches + 4 reduces per layer)
+  if (!Np || !Kp || nprob < 1 || nprob > GROUP_MAX || T < 512) return false;
   for (int j = 0; j < nprob; ++j) {
     if (Np[j] < 256 || Kp[j] < 256 || (Np[j] % 256) || (Kp[j] % 256)) return false;       // 256x256 tiles only
     if ((uint64_t)(T + BKT) * (uint64_t)(Np[j] > Kp[j] ? Np[j] : Kp[j]) * 2 >= PIECE_BYTES) return false;   // 32-bit offsets

@@ -541,6 +541,29 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const long* __restrict_
   }
 }
 
+// index[b] = base + b * stride + argmax_l ids[b][l] (first position of the largest id, as torch.argmax): the EOT row of caption b in
+// a token-major [.., D] activation buffer (modules/module_cross.py:300-303 picks x[arange(b), text.argmax(-1)]).  One wave per
+// caption; L <= 1024.
+__global__ __launch_bounds__(256) void eot_index_kernel(const long* __restrict__ ids, int* __restrict__ index, int b, int L, long base,
+                                                        long stride) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= b) return;
+  long best = -0x7fffffffffffffffL - 1;
+  int pos = 0;
+  for (int l = lane; l < L; l += 64) {
+    const long v = ids[(long)row * L + l];
+    if (v > best) { best = v; pos = l; }           // strictly greater: a lane keeps its first maximum
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const long ob = __shfl_xor(best, o, 64);
+    const int op = __shfl_xor(pos, o, 64);
+    if (ob > best || (ob == best && op < pos)) { best = ob; pos = op; }
+  }
+  if (lane == 0) index[row] = (int)(base + (long)row * stride + pos);
+}
+
 // dtable[id][:] = sum over the rows r with ids[r] == id of dx[r][:]   (fp32 table gradient, dense, zeroed by the caller).
 // Deterministic, no atomics: one workgroup per token row; the row that is the FIRST occurrence of its id owns the id's
 // table row.  It lists the later occurrences in row order (wave ballots), its 8 waves each sum every 8th of them, and
@@ -864,6 +887,13 @@ extern "C" int hmmc_text_embed(const long* ids, const float* table, const float*
   else
     hipLaunchKernelGGL(text_embed_kernel<float>, dim3(grid_for(rows * (D / 8), 256, 4096)), dim3(256), 0, stream, ids, table, pos,
                        (float*)x, rows, L, D, vocab, err_flag);
+  return hmmc_launch_status();
+}
+
+extern "C" int hmmc_eot_index(const long* ids, int* index, int b, int L, long base, long stride, hipStream_t stream) {
+  if (!ids || !index || b <= 0 || L <= 0 || L > 1024) return HMMC_ERR_ARG;
+  if (base < 0 || stride < L || base + (long)b * stride > 0x7fffffffL) return HMMC_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(eot_index_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, ids, index, b, L, base, stride);
   return hmmc_launch_status();
 }
 

@@ -64,23 +64,61 @@ __global__ __launch_bounds__(256) void mt_sumsq_kernel(const long* __restrict__ 
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-// sumsq[t] = sum of the partial sums of tensor t's chunks: chunks tab[t][7] .. + ceil(numel / CHUNK) - 1 of the list, lane l
-// takes chunks l, l + 64, ... in order, then a fixed butterfly.  One wave per tensor.
-__global__ __launch_bounds__(64) void mt_sumsq_finish_kernel(const long* __restrict__ tab, const int* __restrict__ chunk,
-                                                             int nchunks, const float* __restrict__ part, float* __restrict__ sumsq) {
-  const int t = blockIdx.x;
+// Squared norm of tensor t = sum of the partial sums of its chunks: chunks tab[t][7] .. + ceil(numel / CHUNK) - 1 of the list,
+// lane l takes chunks l, l + 64, ... in order, then a fixed butterfly: ONE wave, every lane returns the total.  This is the only
+// place a tensor's partials are added, so every kernel that needs the norm (the finish kernel, the clip coefficient, BertAdam's
+// per-parameter clip) gets the same bits.
+__device__ __forceinline__ float tensor_sumsq(const long* __restrict__ tab, const int* __restrict__ chunk, int nchunks,
+                                              const float* __restrict__ part, int t, int lane) {
   const long* e = tab + (long)t * 8;
   const long first = e[7];
   const long nch = (e[4] + CHUNK - 1) / CHUNK;
-  if (first < 0 || first + nch > nchunks || (nch > 0 && chunk[2 * first] != t)) {      // table without the first-chunk column
-    if (threadIdx.x == 0) sumsq[t] = __builtin_nanf("");
-    return;
-  }
+  if (first < 0 || first + nch > nchunks || (nch > 0 && chunk[2 * first] != t)) return __builtin_nanf("");   // table without the first-chunk column
   float s = 0.f;
-  for (long c = threadIdx.x; c < nch; c += 64) s += part[first + c];
+  for (long c = lane; c < nch; c += 64) s += part[first + c];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (threadIdx.x == 0) sumsq[t] = s;
+  return s;
+}
+
+// sumsq[t] for every tensor.  One wave per tensor.
+__global__ __launch_bounds__(64) void mt_sumsq_finish_kernel(const long* __restrict__ tab, const int* __restrict__ chunk,
+                                                             int nchunks, const float* __restrict__ part, float* __restrict__ sumsq) {
+  const float s = tensor_sumsq(tab, chunk, nchunks, part, blockIdx.x, threadIdx.x);
+  if (threadIdx.x == 0) sumsq[blockIdx.x] = s;
+}
+
+constexpr int FINISH_COEF_MAX_T = 4096;
+// mt_sumsq_finish_kernel and mt_clip_coef_kernel in ONE single-block launch (16 waves share the tensors): sumsq[t] for every
+// tensor, then out[0] = clip coefficient, out[1] = total norm - the same sums in the same order as the two kernels.
+__global__ __launch_bounds__(1024) void mt_finish_coef_kernel(const long* __restrict__ tab, const int* __restrict__ chunk, int nchunks,
+                                                              const float* __restrict__ part, float* __restrict__ sumsq, int T,
+                                                              float max_norm, float* __restrict__ out) {
+  __shared__ float red[4];
+  __shared__ float ssq[FINISH_COEF_MAX_T];           // the norms travel to the second half through LDS, not through the global array
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = wave; t < T; t += 16) {
+    const float s = tensor_sumsq(tab, chunk, nchunks, part, t, lane);
+    if (lane == 0) { sumsq[t] = s; ssq[t] = s; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {                          // exactly mt_clip_coef_kernel's arithmetic: 256 threads, block_sum's order
+    float s = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) {
+      float n = sqrtf(ssq[t]);
+      if (tab[(long)t * 8 + 5] == 0) n = r16(n);
+      s += n * n;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float total = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float c = max_norm / (total + 1e-6f);
+    out[0] = c < 1.0f ? c : 1.0f;
+    out[1] = total;
+  }
 }
 
 // out[0] = clip coefficient, out[1] = total norm (torch.nn.utils.clip_grad_norm_ semantics: per-tensor
@@ -151,6 +189,9 @@ constexpr int MAX_GROUPS = 32;
 struct AdamGroups { float v[MAX_GROUPS][8]; };
 
 // index (optional): sumsq is another table's array and tensor t's entry is sumsq[index[t]] (hmmc_mt_bertadam_ext)
+// The per-parameter clip multiplies by c = min(1, max_grad_norm / (norm + 1e-6)); where c is exactly 1 - every tensor whose norm
+// is below max_grad_norm, i.e. every tensor right after a global clip to the same bound - g * 1 is g and the gradient is not
+// written back (the reference's in-place clip leaves the same bits): 6 instead of 7 passes over the parameter bytes.
 __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict__ tab, AdamGroups groups,
                                                           const int* __restrict__ chunk, const float* __restrict__ sumsq_,
                                                           const int* __restrict__ index) {
@@ -176,9 +217,10 @@ __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict
       c = r16(maxn / r16(nrm + 1e-6f));
       c = c < 1.0f ? c : 1.0f;
     }
+    const bool wr_g = maxn > 0.f && c != 1.0f;     // fp16(g * 1) == g
     auto upd = [&](half_t& pp, half_t& gg, half_t& mm, half_t& vv) {
       float gi = (float)gg;
-      if (maxn > 0.f) { gi = r16s(gi * c); gg = (half_t)gi; }
+      if (wr_g) { gi = r16s(gi * c); gg = (half_t)gi; }
       // add_(g, alpha) is a true fma on the reference's CPU path; addcmul_ is (value*g)*g then an add
       float mi = r16s(__fmaf_rn(ob1h, gi, r16s((float)mm * b1)));
       float vi = r16s(r16s((float)vv * b2) + opq(opq(ob2 * gi) * gi));
@@ -197,7 +239,7 @@ __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict
 #pragma unroll
       for (int j = 0; j < 8; ++j) { half_t a = P[j], b = G[j], cc = Mv[j], d = Vv[j]; upd(a, b, cc, d); P[j] = a; G[j] = b; Mv[j] = cc; Vv[j] = d; }
       *reinterpret_cast<h8*>(p + i) = P;
-      if (maxn > 0.f) *reinterpret_cast<h8*>(g + i) = G;
+      if (wr_g) *reinterpret_cast<h8*>(g + i) = G;
       *reinterpret_cast<h8*>(m + i) = Mv;
       *reinterpret_cast<h8*>(v + i) = Vv;
     }
@@ -212,9 +254,10 @@ __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict
       c = maxn / (sqrtf(sumsq[t]) + 1e-6f);
       c = c < 1.0f ? c : 1.0f;
     }
+    const bool wr_g = maxn > 0.f && c != 1.0f;     // g * 1.0f == g
     auto upd = [&](float& pp, float& gg, float& mm, float& vv) {
       float gi = gg;
-      if (maxn > 0.f) { gi = gi * c; gg = gi; }
+      if (wr_g) { gi = gi * c; gg = gi; }
       float mi = __fmaf_rn(ob1, gi, opq(mm * b1));
       float vi = opq(vv * b2) + opq(opq(ob2 * gi) * gi);
       float u = mi / opq(sqrtf(vi) + eps);
@@ -230,7 +273,7 @@ __global__ __launch_bounds__(256) void mt_bertadam_kernel(const long* __restrict
 #pragma unroll
       for (int j = 0; j < 4; ++j) { float a = P[j], b = G[j], cc = Mv[j], d = Vv[j]; upd(a, b, cc, d); P[j] = a; G[j] = b; Mv[j] = cc; Vv[j] = d; }
       *reinterpret_cast<f4*>(p + i) = P;
-      if (maxn > 0.f) *reinterpret_cast<f4*>(g + i) = G;
+      if (wr_g) *reinterpret_cast<f4*>(g + i) = G;
       *reinterpret_cast<f4*>(m + i) = Mv;
       *reinterpret_cast<f4*>(v + i) = Vv;
     }
@@ -301,8 +344,12 @@ extern "C" int hmmc_mt_clip_grad_norm(const long* tab, const int* chunk, int nch
                                       float* out, hipStream_t stream) {
   if (!tab || !chunk || !sumsq || !out || nchunks <= 0 || T <= 0) return HMMC_ERR_ARG;
   hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq + T);
-  hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq);
-  hipLaunchKernelGGL(mt_clip_coef_kernel, dim3(1), dim3(256), 0, stream, tab, (const float*)sumsq, T, max_norm, out);
+  if (T <= FINISH_COEF_MAX_T) {
+    hipLaunchKernelGGL(mt_finish_coef_kernel, dim3(1), dim3(1024), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq, T, max_norm, out);
+  } else {
+    hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq);
+    hipLaunchKernelGGL(mt_clip_coef_kernel, dim3(1), dim3(256), 0, stream, tab, (const float*)sumsq, T, max_norm, out);
+  }
   hipLaunchKernelGGL(mt_scale_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, (const float*)out, (const float*)nullptr, (float*)nullptr);
   return hmmc_launch_status();
 }
@@ -314,8 +361,12 @@ extern "C" int hmmc_mt_clip_grad_norm_keep(const long* tab, const int* chunk, in
                                            float* out, float* sumsq_after, hipStream_t stream) {
   if (!tab || !chunk || !sumsq || !out || !sumsq_after || nchunks <= 0 || T <= 0) return HMMC_ERR_ARG;
   hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, sumsq + T);
-  hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq);
-  hipLaunchKernelGGL(mt_clip_coef_kernel, dim3(1), dim3(256), 0, stream, tab, (const float*)sumsq, T, max_norm, out);
+  if (T <= FINISH_COEF_MAX_T) {
+    hipLaunchKernelGGL(mt_finish_coef_kernel, dim3(1), dim3(1024), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq, T, max_norm, out);
+  } else {
+    hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq + T), sumsq);
+    hipLaunchKernelGGL(mt_clip_coef_kernel, dim3(1), dim3(256), 0, stream, tab, (const float*)sumsq, T, max_norm, out);
+  }
   hipLaunchKernelGGL(mt_scale_kernel, dim3(nchunks), dim3(256), 0, stream, tab, chunk, (const float*)out, (const float*)(sumsq + T),
                      sumsq_after + T);
   hipLaunchKernelGGL(mt_sumsq_finish_kernel, dim3(T), dim3(64), 0, stream, tab, chunk, nchunks, (const float*)(sumsq_after + T),

@@ -161,7 +161,7 @@ class TextEmbedFn(torch.autograd.Function):
         D = dx.shape[-1]
         dtable = ops.text_embed_bwd(ids, dx, vocab)
         dpos = torch.zeros((ctx_len, D), dtype=torch.float32, device=dx.device)
-        dpos[:L] = ops.colsum(dx.view(b, L * D), out_dtype=torch.float32, round_f16=dx.dtype == torch.float16).view(L, D)
+        ops.colsum(dx.view(b, L * D), out_dtype=torch.float32, round_f16=dx.dtype == torch.float16, out=dpos[:L].view(-1))
         return None, dtable, dpos, None
 
 
@@ -340,12 +340,16 @@ class LnProjFn(torch.autograd.Function):
     """feat = float( LN(x[rows]) @ proj ); rows = row_index (CLS / EOT rows) or all rows."""
 
     @staticmethod
-    def forward(ctx, x, row_index, ln_w, ln_b, proj):
+    def forward(ctx, x, row_index, ln_w, ln_b, proj, rows_only=False):
+        """rows_only: the producer of x reads its gradient at the rows of row_index ALONE (a lead_only tower: hmmc_tower_bwd
+        reads dy at the class-token rows only), so the backward leaves the other rows of dx unwritten instead of zero-filling the
+        whole [tokens, D] buffer (236 MB at config 2)."""
         D, E = proj.shape
         y, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, 1e-5, row_index=row_index)
         R = y.shape[0]
         if y.dtype != proj.dtype:
             raise RuntimeError(f"expected the activations ({y.dtype}) and the projection ({proj.dtype}) to have the same dtype")
+        ctx.rows_only = bool(rows_only and row_index is not None)
         ctx.save_for_backward(x, row_index, ln_w, proj, y, mean, rstd)
         if proj.dtype == torch.float32:
             return ops.dgrad_f32(y, proj)                 # y @ proj, fp32 regime
@@ -365,11 +369,11 @@ class LnProjFn(torch.autograd.Function):
             dy = ops.gemm_f16(d16, proj, R, D, E, a_kmajor=True, b_kmajor=True)      # dy = d16 @ proj^T
             dproj = ops.gemm_f16(y, d16, D, E, R, a_kmajor=False, b_kmajor=False)    # y^T d16
         if row_index is not None:
-            dx = torch.zeros_like(x)
+            dx = torch.empty_like(x) if ctx.rows_only else torch.zeros_like(x)
             dx, dlw, dlb = ops.layernorm_bwd(dy, x, ln_w, mean, rstd, row_index=row_index, dx=dx)
         else:
             dx, dlw, dlb = ops.layernorm_bwd(dy, x, ln_w, mean, rstd)
-        return dx, None, dlw, dlb, dproj
+        return dx, None, dlw, dlb, dproj, None
 
 
 class TemporalFn(torch.autograd.Function):
@@ -404,8 +408,11 @@ class TemporalFn(torch.autograd.Function):
         if not nl:
             return dvf.view(b, F, E), None, None
         dx, grads = _tower_backward(dvf, ctx.x0, params, ctx.acts, b, F, heads, False, True)
-        dpos = torch.zeros_like(pos_table)
-        dpos[:F] = ops.colsum(dx.view(b, F * E)).view(F, E)
+        if F == pos_table.shape[0]:
+            dpos = ops.colsum(dx.view(b, F * E)).view(F, E)
+        else:
+            dpos = torch.zeros_like(pos_table)
+            ops.colsum(dx.view(b, F * E), out=dpos[:F].view(-1))
         du = dx + dvf                                   # through (u + pos) and through the residual
         ctx.acts = ctx.x0 = None
         return (du.view(b, F, E), None, dpos, *grads)

@@ -190,12 +190,17 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
         """gather keys from every rank, normalise, overwrite queue columns [ptr, ptr+B) (frame queues: [ptr*F, (ptr+B)*F))
         (reference modules/modeling.py:244-284)."""
         b, F, E = frame_fea_k.shape
-        packed = torch.cat([v_fea_k, tag_fea_k, title_fea_k, frame_fea_k.reshape(b, F * E), frame_proj_k.reshape(b, F * E)], dim=1)
-        packed = dist_collect(packed)
-        B = packed.shape[0]
-        v, tag, title = packed[:, :E], packed[:, E:2 * E], packed[:, 2 * E:3 * E]
-        fr = packed[:, 3 * E:3 * E + F * E].reshape(B * F, E)
-        fp = packed[:, 3 * E + F * E:].reshape(B * F, E)
+        if Fn.collectives_active():
+            packed = torch.cat([v_fea_k, tag_fea_k, title_fea_k, frame_fea_k.reshape(b, F * E), frame_proj_k.reshape(b, F * E)], dim=1)
+            packed = dist_collect(packed)
+            B = packed.shape[0]
+            v, tag, title = packed[:, :E], packed[:, E:2 * E], packed[:, 2 * E:3 * E]
+            fr = packed[:, 3 * E:3 * E + F * E].reshape(B * F, E)
+            fp = packed[:, 3 * E + F * E:].reshape(B * F, E)
+        else:                                            # one rank: nothing to gather, nothing to pack and slice apart again
+            B = b
+            v, tag, title = v_fea_k, tag_fea_k, title_fea_k
+            fr, fp = frame_fea_k.reshape(B * F, E), frame_proj_k.reshape(B * F, E)
         ptr_ = self._queue_ptr_host if self._queue_ptr_host is not None else int(self.queue_ptr)
         ops.enqueue(v.contiguous(), self.queue_v_cross_ng, ptr_)
         ops.enqueue(tag.contiguous(), self.queue_tag_cross_ng, ptr_)
@@ -350,9 +355,11 @@ class BirdPreTrainedModel(CLIP4ClipPreTrainedModel):
                     t.record_stream(cur)
         # The losses (and their backward, which runs after the enqueue below) must see the OLD negatives: one
         # snapshot per queue per step (the reference clones the queue inside each of its 48 contrastive_loss calls).
-        q_proj, q_cross = self.queue_frame_proj_ng.clone(), self.queue_frame_cross_ng.clone()
-        q_title, q_v = self.queue_title_cross_ng.clone(), self.queue_v_cross_ng.clone()
-        q_tag = self.queue_tag_cross_ng.clone() if bird else None
+        names = ["queue_frame_proj_ng", "queue_frame_cross_ng", "queue_title_cross_ng", "queue_v_cross_ng"] + (["queue_tag_cross_ng"] if bird else [])
+        snaps = [torch.empty_like(getattr(self, n)) for n in names]
+        torch._foreach_copy_(snaps, [getattr(self, n) for n in names])         # one multi-tensor launch for the four / five snapshots
+        q_proj, q_cross, q_title, q_v = snaps[:4]
+        q_tag = snaps[4] if bird else None
         loss_FAM = self.frame_self_loss(frame_pred, frame_proj_k, q_proj)
         v_title = self.contrastive_loss(v_fea, title_fea_k, q_title) + self.contrastive_loss(title_fea, v_fea_k, q_v)
         if bird:
@@ -496,10 +503,12 @@ class BirdModel(BirdPreTrainedModel):
             query_output = self.text_encoder(query_ids, query_mask)
             visual_output, frame_output = self.visual_encoder(video, video_frame)
         b, F, E = frame_output.shape
-        # one packed all-gather [b, (F+2)*E] instead of the reference's three (modules/modeling.py:698-700)
-        packed = dist_collect(torch.cat([visual_output, query_output, frame_output.reshape(b, F * E)], dim=1))
-        visual_output, query_output = packed[:, :E], packed[:, E:2 * E]
-        frame_output = packed[:, 2 * E:].reshape(-1, F, E)
+        if Fn.collectives_active():
+            # one packed all-gather [b, (F+2)*E] instead of the reference's three (modules/modeling.py:698-700)
+            packed = dist_collect(torch.cat([visual_output, query_output, frame_output.reshape(b, F * E)], dim=1))
+            visual_output, query_output = packed[:, :E], packed[:, E:2 * E]
+            frame_output = packed[:, 2 * E:].reshape(-1, F, E)
+        # (one rank: the gather is the identity - no packing, slicing and re-packing of the features and of their gradients)
         scale = min(math.exp(float(self.text_encoder.logit_scale)), 100.0)
         use_frames = bool(self.task_config.use_frame_fea)
         loss = Fn.FinetuneHeadFn.apply(query_output, visual_output, frame_output if use_frames else None,

@@ -148,7 +148,8 @@ class VisualEncoder(nn.Module):
             hidden = Fn.LnProjFn.apply(tokens, None, v.ln_post.weight, v.ln_post.bias, v.proj).view(n, L, -1)
             return hidden[:, 0, :], hidden
         idx = torch.arange(n, device=tokens.device, dtype=torch.int32) * L
-        return Fn.LnProjFn.apply(tokens, idx, v.ln_post.weight, v.ln_post.bias, v.proj)
+        # the fp16 tower ran lead_only: its backward reads the gradient of `tokens` at the class rows alone
+        return Fn.LnProjFn.apply(tokens, idx, v.ln_post.weight, v.ln_post.bias, v.proj, tokens.dtype == torch.float16)
 
 
 class TextEncoder(nn.Module):
@@ -187,7 +188,7 @@ class TextEncoder(nn.Module):
         if _want in ("both", "hidden"):
             hidden = Fn.LnProjFn.apply(x, None, self.ln_final.weight, self.ln_final.bias, self.text_projection).view(b, L, -1)
         if _want in ("both", "feat"):
-            idx = (torch.arange(b, device=text.device) * L + text.argmax(dim=-1)).to(torch.int32)   # EOT = largest id
+            idx = ops.eot_index(text.contiguous())                                                  # EOT = largest id
             feat = Fn.LnProjFn.apply(x, idx, self.ln_final.weight, self.ln_final.bias, self.text_projection)
         if return_hidden:
             return feat, hidden
@@ -210,14 +211,14 @@ def _encode_many(self, texts, wants):
     outs, row0 = [], 0
     for t, want in zip(texts, wants):
         b, L = t.shape
-        seq = torch.arange(row0, row0 + b, device=t.device)
         if want == "feat":
-            idx = (seq * Lmax + t.argmax(dim=-1)).to(torch.int32)                # EOT = largest id
+            idx = ops.eot_index(t.contiguous(), base=row0 * Lmax, stride=Lmax)   # EOT = largest id
             outs.append(Fn.LnProjFn.apply(x, idx, self.ln_final.weight, self.ln_final.bias, self.text_projection))
         elif L == Lmax:
             rows = x[row0 * Lmax:(row0 + b) * Lmax]
             outs.append(Fn.LnProjFn.apply(rows, None, self.ln_final.weight, self.ln_final.bias, self.text_projection).view(b, L, -1))
         else:
+            seq = torch.arange(row0, row0 + b, device=t.device)
             idx = (seq[:, None] * Lmax + torch.arange(L, device=t.device)[None, :]).reshape(-1).to(torch.int32)
             outs.append(Fn.LnProjFn.apply(x, idx, self.ln_final.weight, self.ln_final.bias, self.text_projection).view(b, L, -1))
         row0 += b

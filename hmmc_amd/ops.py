@@ -290,13 +290,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, row_index=None, dx=None, 
     return (dx, dgamma, dbeta, dxs) if want_colsum else (dx, dgamma, dbeta)
 
 
-def colsum(x2d, out_dtype=None, round_f16=False):
-    """out[n] = sum_m x[m][n] (fp32 accumulation)."""
+def colsum(x2d, out_dtype=None, round_f16=False, out=None):
+    """out[n] = sum_m x[m][n] (fp32 accumulation).  out: a contiguous [N] destination (a slice of a larger buffer)."""
     M, N = x2d.shape
     in_dt = 0 if x2d.dtype == torch.float16 else 1
-    out_dtype = out_dtype or x2d.dtype
+    out_dtype = out_dtype or (out.dtype if out is not None else x2d.dtype)
     _chk(x2d, x2d.dtype, "x")
-    out = torch.empty(N, dtype=out_dtype, device=x2d.device)
+    if out is None:
+        out = torch.empty(N, dtype=out_dtype, device=x2d.device)
+    else:
+        _chk(out, out_dtype, "out")
+        assert out.numel() == N
     wsb = query("hmmc_colsum_workspace", M, N)
     ws = workspace(wsb, x2d.device, "colsum")
     call("hmmc_colsum", ptr(x2d), ptr(out), M, N, N, in_dt, 0 if out_dtype == torch.float16 else 1, int(round_f16),
@@ -377,6 +381,15 @@ def text_embed(ids, table, pos, dtype=torch.float16):
     call("hmmc_text_embed", ptr(ids), ptr(table), ptr(pos), ptr(x), b * L, L, D, table.shape[0], ptr(device_error_flag(ids.device)),
          _dt(dtype))
     return x
+
+
+def eot_index(ids, base=0, stride=None):
+    """int32 [b]: base + i * stride + argmax(ids[i]) - row of caption i's EOT token (largest id, first occurrence)."""
+    _chk(ids, torch.int64, "ids")
+    b, L = ids.shape
+    out = torch.empty(b, dtype=torch.int32, device=ids.device)
+    call("hmmc_eot_index", ptr(ids), ptr(out), b, L, int(base), int(L if stride is None else stride))
+    return out
 
 
 def text_embed_bwd(ids, dx, vocab):

@@ -73,7 +73,7 @@ int hmmc_gemm_profile_stop(double* flops, double* bytes, double* seconds, long* 
  * items of all problems share one persistent grid and one K split (chosen so that their tiles together fill the chip), fp32
  * partial slabs in `workspace`, one reduce.  dY / X / dW / Np / Kp: HOST arrays of nprob device pointers / sizes.
  * hmmc_gemm_f16_wgrad_group_workspace returns the workspace bytes, or 0 when the shapes should take one hmmc_gemm_f16 call per
- * gradient instead (dimensions that are not multiples of 256, fewer than 2048 tokens, operands of 2 GiB and more). */
+ * gradient instead (dimensions that are not multiples of 256, fewer than 512 tokens, operands of 2 GiB and more). */
 size_t hmmc_gemm_f16_wgrad_group_workspace(const int* Np, const int* Kp, int nprob, int T);
 /* dW32 (may be NULL; HOST array of nprob device pointers, entries may be NULL): problem j with dW32[j] != NULL leaves as dense
  * fp32 sums [Np_j][Kp_j] there instead of fp16 in dW[j] - the folded weight gradients that hmmc_fold_grad_finish completes. */
@@ -182,6 +182,10 @@ int hmmc_vit_embed_ln(void* x0, const float* cls, const float* pos, const float*
  * *err_flag (device int, may be NULL) is set to 1 for the host to check. */
 int hmmc_text_embed(const long* ids, const float* table, const float* pos, void* x, long rows, int L, int D, long vocab,
                     int* err_flag, int out_dtype, hmmc_stream_t stream);
+/* index[i] = base + i * stride + argmax_l ids[i][l] (the first position of the largest id, torch.argmax's tie rule), i < b: the row
+ * of caption i's EOT token - CLIP's largest id - in a token-major activation buffer whose captions sit `stride` rows apart
+ * (modules/module_cross.py:300-303: x[arange(b), text.argmax(-1)]); ONE launch for the reference's arange / argmax / add. */
+int hmmc_eot_index(const long* ids, int* index, int b, int L, long base, long stride, hmmc_stream_t stream);
 /* dense fp32 embedding gradient: dtable[id] = sum of dx[r] over the rows with ids[r] == id (dtable zeroed by the caller;
  * ids outside [0, vocab) contribute nothing).  No atomics: bit-identical from run to run.  dx_dtype: 0 fp16, 1 fp32. */
 int hmmc_text_embed_bwd(const long* ids, const void* dx, float* dtable, long rows, int D, long vocab, int dx_dtype,

@@ -815,6 +815,37 @@ def test_optimizer_takes_the_norms_the_clip_left_bit_identical(max_norm, scales)
     assert all(torch.equal(a, b) for a, b in zip(ref, got_s)), "step on another stream"
 
 
+def test_class_token_gradient_buffer_is_not_zero_filled_and_not_read(monkeypatch):
+    """Round 5: the backward of ln_post / proj hands the frame tower a gradient buffer in which only the class-token rows are
+    written (LnProjFn rows_only; the tower ran lead_only and reads those rows alone, include/hmmc_hip.h) instead of zero-filling
+    [tokens, D].  Loss and every gradient must be bit-identical to the zero-filled form, with the allocator's free blocks
+    poisoned with NaN right before the backward."""
+    model, sd = build(synth.TINY)
+    batch = [t.to(DEV) for t in synth.finetune_batch(6, 4, 32, tag="rows_only")]
+
+    def run(rows_only):
+        orig = Fn.LnProjFn.forward
+
+        def fwd(ctx, x, row_index, ln_w, ln_b, proj, ro=False):
+            return orig(ctx, x, row_index, ln_w, ln_b, proj, ro and rows_only)
+        monkeypatch.setattr(Fn.LnProjFn, "forward", staticmethod(fwd))
+        model.zero_grad(set_to_none=True)
+        loss = model(*batch, 1)
+        torch.cuda.synchronize()
+        junk = [torch.full((n,), float("nan"), dtype=torch.float16, device=DEV) for n in (6 * 4 * 50 * 128, 6 * 4 * 50 * 128, 1 << 20)]
+        del junk                                            # the caching allocator hands these blocks to the backward's empty_like
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert torch.equal(l0, l1)
+    assert all(torch.isfinite(g).all() for g in g1.values())
+    bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+    assert not bad, bad[:5]
+
+
 def _clip_skip_then_step(shared, via_optimizer_zero_grad):
     """clip, NO step (a skipped iteration), gradients dropped, new gradients (other values, version 0 again, and - the caching
     allocator being what it is - at the old addresses), step WITHOUT a clip."""
