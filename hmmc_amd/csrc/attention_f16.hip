@@ -77,14 +77,19 @@ __device__ __forceinline__ void lead_to_frags(half_t* tile, const u4v (&raw)[2],
 // hmmc_tower_fwd with lead_only): the SAME instruction sequence on query tile 0 with the tile's other fifteen rows as zeros - a
 // query's column of every MFMA is independent of the other columns, so row 0 of the output and its log-sum-exp are bit-identical
 // to the all-query kernel's - and only that row is stored.  The Q columns of the other tokens are never read.
+#if defined(HMMC_SCRATCH) && defined(HMMC_ATTN_FWD_WPB)
+constexpr int FWD_WPB = HMMC_ATTN_FWD_WPB;      // scratch experiments: waves per workgroup of the forward
+#else
+constexpr int FWD_WPB = 4;
+#endif
 template <int KT, bool LEAD = false>
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * FWD_WPB, 3) void attn_fwd_kernel(AttnArgs p) {
   constexpr int LP = 16 * KT;
   constexpr int QT = LEAD ? 1 : KT;              // query tiles computed
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long pair = (long)blockIdx.x * 4 + wid;
+  const long pair = (long)blockIdx.x * FWD_WPB + wid;
   if (pair >= (long)p.nseq * p.H) return;
   const int n = (int)(pair / p.H), h = (int)(pair % p.H);
   const int D = p.H * DH, L = p.L;
@@ -189,15 +194,23 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs p) {
 //    query has lse = +inf (probability exactly 0, like the queries past L), phase 1 runs for query tile 0 and phase 2 over the
 //    first pair of query tiles; dK and dV are written for every token, dQ for query 0 only - the Q columns of the other rows
 //    of dqkv are NOT written (their gradient is exactly zero; the tower's data and weight gradients do not read them).
+// Workgroups of TWO waves (round 5; four until then): a workgroup's LDS and wave slots come free when its last wave ends, so
+// smaller groups refill a CU's eight slots sooner (scratch/attn_abl.sh, 3 072 x 50 x 12: 430 us with 4 waves per workgroup, 415 with
+// 2, 412 with 1, 468 with 8).  The same ablations say where the time goes: 232 us with the arithmetic removed (loads, fragment
+// shuffles and stores only), -82 / -100 us with the dV / dK pass of phase 2 removed - load time and compute time ADD.  A
+// persistent, software-pipelined form (next pair's operands by LDS-DMA under the current pair's phases; scratch/attn_bwd_pipe.patch,
+// bit-identical on its first run) needs 40 KiB of LDS per wave = one wave per SIMD, and one wave's dependent MFMA / exp / LDS
+// chain takes 16.5 us per pair alone (594 us); two waves per SIMD sharing the pipes are what hides it here (23 us per pair and wave).
+constexpr int BWD_WPB = 2;
 template <int KT, bool LEAD = false>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * BWD_WPB, 2) void attn_bwd_kernel(AttnArgs p) {
   constexpr int LP = 16 * KT;
   constexpr int QT = LEAD ? 1 : KT;              // query tiles with a non-zero output gradient
   constexpr int WAVE_LDS = LP * LDS_STRIDE * 2 + 16 * LDS_STRIDE * 2 + 2 * LP * 4;     // tile + store scratch + lse[LP] + delta[LP]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long pair = (long)blockIdx.x * 4 + wid;
+  const long pair = (long)blockIdx.x * BWD_WPB + wid;
   if (pair >= (long)p.nseq * p.H) return;
   const int n = (int)(pair / p.H), h = (int)(pair % p.H);
   const int D = p.H * DH, L = p.L;
@@ -378,9 +391,9 @@ extern "C" int hmmc_attention_f16_fwd(const void* qkv, void* out, float* lse, in
   AttnArgs p{};
   p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = lse; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   long pairs = (long)nseq * H;
-  dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
-  if (L <= 32) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, 4 * (32 + 16) * LDS_STRIDE * 2, stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, 4 * (64 + 16) * LDS_STRIDE * 2, stream, p);
+  dim3 grid((unsigned)((pairs + FWD_WPB - 1) / FWD_WPB)), block(64 * FWD_WPB);
+  if (L <= 32) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, FWD_WPB * (32 + 16) * LDS_STRIDE * 2, stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, FWD_WPB * (64 + 16) * LDS_STRIDE * 2, stream, p);
   return hmmc_launch_status();
 }
 
@@ -415,9 +428,9 @@ static int attention_bwd(const void* qkv, const void* out, const float* lse, con
   p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = (float*)lse; p.dout = (const half_t*)dout;
   p.dqkv = (half_t*)dqkv; p.dbias = dbias_partial; p.rowstat = rowstat; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   long pairs = (long)nseq * H;
-  dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
-  if (L <= 32) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, 4 * ((32 + 16) * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);
-  else hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, block, 4 * ((64 + 16) * LDS_STRIDE * 2 + 2 * 64 * 4), stream, p);
+  dim3 grid((unsigned)((pairs + BWD_WPB - 1) / BWD_WPB)), block(64 * BWD_WPB);
+  if (L <= 32) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, BWD_WPB * ((32 + 16) * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);
+  else hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, block, BWD_WPB * ((64 + 16) * LDS_STRIDE * 2 + 2 * 64 * 4), stream, p);
   return hmmc_launch_status();
 }
 
@@ -432,9 +445,9 @@ extern "C" int hmmc_attention_f16_fwd_lead(const void* qkv, void* out, float* ls
   p.qkv = (const half_t*)qkv; p.out = (half_t*)out; p.lse = lse; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   if (L > 64) return hmmc_attention_long_fwd(p, stream, true);
   long pairs = (long)nseq * H;
-  dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
-  if (L <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), grid, block, 4 * (32 + 16) * LDS_STRIDE * 2, stream, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<4, true>), grid, block, 4 * (64 + 16) * LDS_STRIDE * 2, stream, p);
+  dim3 grid((unsigned)((pairs + FWD_WPB - 1) / FWD_WPB)), block(64 * FWD_WPB);
+  if (L <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), grid, block, FWD_WPB * (32 + 16) * LDS_STRIDE * 2, stream, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<4, true>), grid, block, FWD_WPB * (64 + 16) * LDS_STRIDE * 2, stream, p);
   return hmmc_launch_status();
 }
 
@@ -452,8 +465,8 @@ extern "C" int hmmc_attention_f16_bwd_lead(const void* qkv, const void* out, con
   p.dqkv = (half_t*)dqkv; p.dbias = dbias_partial; p.rowstat = rowstat; p.nseq = nseq; p.L = L; p.H = H; p.causal = causal;
   if (L > 64) return hmmc_attention_long_bwd(p, stream, true);
   long pairs = (long)nseq * H;
-  dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
-  if (L <= 32) hipLaunchKernelGGL((attn_bwd_kernel<2, true>), grid, block, 4 * ((32 + 16) * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);
-  else hipLaunchKernelGGL((attn_bwd_kernel<4, true>), grid, block, 4 * ((64 + 16) * LDS_STRIDE * 2 + 2 * 64 * 4), stream, p);
+  dim3 grid((unsigned)((pairs + BWD_WPB - 1) / BWD_WPB)), block(64 * BWD_WPB);
+  if (L <= 32) hipLaunchKernelGGL((attn_bwd_kernel<2, true>), grid, block, BWD_WPB * ((32 + 16) * LDS_STRIDE * 2 + 2 * 32 * 4), stream, p);
+  else hipLaunchKernelGGL((attn_bwd_kernel<4, true>), grid, block, BWD_WPB * ((64 + 16) * LDS_STRIDE * 2 + 2 * 64 * 4), stream, p);
   return hmmc_launch_status();
 }
