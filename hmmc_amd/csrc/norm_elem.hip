@@ -422,6 +422,9 @@ __global__ __launch_bounds__(256) void vit_embed_kernel(T* __restrict__ x, const
 // row back (the backward of ln_pre needs it), normalises it in registers and writes y; `stat` (optional) receives
 // (rstd, -rstd mean) of the ROUNDED y row for the first folded GEMM of the tower (ln_fold.hip).  Saves the 240 us in-place
 // pass and the statistics pass at 153 600 x 768.  Structure of ln_fwd_kernel: next row requested before this one is reduced.
+// FIXPOS: the grid's wave count is a multiple of L, so a wave meets ONE position all launch long: its positional row (3 KiB of
+// fp32 per 1.5 KiB row of x0, from L2) is read once instead of per row (round 5: 162 -> see DESIGN.md section 6).
+template <bool FIXPOS>
 __global__ __launch_bounds__(256) void vit_embed_ln_kernel(half_t* __restrict__ x0, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, half_t* __restrict__ y,
@@ -446,17 +449,22 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(half_t* __restrict__ 
   if (row >= rows) return;
   h8 cur[MAXV], nxt[MAXV];
   f4 pc[MAXV][2], pn[MAXV][2];
-  auto load_row = [&](int r, h8 (&t)[MAXV], f4 (&pp)[MAXV][2]) {
-    const half_t* xr = x0 + (long)r * D;
+  auto load_pos = [&](int r, f4 (&pp)[MAXV][2]) {
     const float* pr = pos + (long)(r % L) * D;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      t[i] = *reinterpret_cast<const h8*>(xr + ce[i]);
       pp[i][0] = *reinterpret_cast<const f4*>(pr + ce[i]);
       pp[i][1] = *reinterpret_cast<const f4*>(pr + ce[i] + 4);
     }
   };
+  auto load_row = [&](int r, h8 (&t)[MAXV], f4 (&pp)[MAXV][2]) {
+    const half_t* xr = x0 + (long)r * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) t[i] = *reinterpret_cast<const h8*>(xr + ce[i]);
+    if constexpr (!FIXPOS) load_pos(r, pp);
+  };
   load_row(row, cur, pc);
+  if constexpr (FIXPOS) load_pos(row, pc);               // row % L is the same for every row this wave meets
   for (; row < rows; row += nwaves) {
     load_row(min(row + nwaves, rows - 1), nxt, pn);
     const bool is_cls = (row % L) == 0;
@@ -506,7 +514,10 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(half_t* __restrict__ 
       if (lane == 0) *reinterpret_cast<f2*>(stat + 2 * (size_t)row) = f2{yr_, -yr_ * ym};
     }
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) { cur[i] = nxt[i]; pc[i][0] = pn[i][0]; pc[i][1] = pn[i][1]; }
+    for (int i = 0; i < MAXV; ++i) {
+      cur[i] = nxt[i];
+      if constexpr (!FIXPOS) { pc[i][0] = pn[i][0]; pc[i][1] = pn[i][1]; }
+    }
   }
 }
 
@@ -698,8 +709,9 @@ extern "C" int hmmc_layernorm_fwd(const void* x, const float* gamma, const float
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return HMMC_ERR_ARG;
   int vn = dtype == 0 ? 8 : 4;
   if (D % vn || D > LN_MAXD || in_stride % vn) return HMMC_ERR_UNSUPPORTED;
-  // 8 rows per wave at least (gamma / beta are loaded once per wave), at most 8 workgroups per CU
-  int nb = (rows + 31) / 32;
+  // 8 rows per wave at least (gamma / beta are loaded once per wave; 2 rows per wave up to 4 096 rows, where the chip is
+  // otherwise idle and the rows of a wave are a latency chain), at most 8 workgroups per CU
+  int nb = rows <= 4096 ? (rows + 7) / 8 : (rows + 31) / 32;
   const int cap = hmmc_num_cus() * 8;
   if (nb > cap) nb = cap;
   dim3 grid(nb < 1 ? 1 : nb), block(256);
@@ -717,7 +729,9 @@ extern "C" int hmmc_layernorm_fwd(const void* x, const float* gamma, const float
 // than are resident at once (a second, partial round of blocks would leave most CUs idle at the end)
 constexpr int LN_BWD_BLOCKS_PER_CU = 3;      // = the second __launch_bounds__ argument of ln_bwd_kernel: one resident round
 static inline int ln_bwd_blocks(int rows) {
-  int nb = (rows + 31) / 32;
+  // (up to 4 096 rows - the temporal transformer, the text tower at small batches - two rows per wave: at 384 rows 12 workgroups
+  // walked 8 rows per wave one after the other on an otherwise idle chip, 20 us)
+  int nb = rows <= 4096 ? (rows + 7) / 8 : (rows + 31) / 32;
   const int cap = hmmc_num_cus() * LN_BWD_BLOCKS_PER_CU;
   if (nb > cap) nb = cap;
   return nb < 1 ? 1 : nb;
@@ -873,8 +887,18 @@ extern "C" int hmmc_vit_embed_ln(void* x0, const float* cls, const float* pos, c
   int nb = (rows + 31) / 32;
   const int cap = hmmc_num_cus() * 8;
   if (nb > cap) nb = cap;
-  hipLaunchKernelGGL(vit_embed_ln_kernel, dim3(nb < 1 ? 1 : nb), dim3(256), 0, stream, (half_t*)x0, cls, pos, gamma, beta, (half_t*)y,
-                     mean, rstd, stat, rows, L, D, eps, eps, write_x0);
+  if (nb < 1) nb = 1;
+  // a grid whose 4 nb waves are a multiple of L keeps every wave on one position: the largest such nb within the cap, if it
+  // still fills the chip (ViT-B/32: L = 50 -> multiples of 25; ViT-B/16: L = 197 -> multiples of 197)
+  const int unit = L / ((L % 4 == 0) ? 4 : (L % 2 == 0) ? 2 : 1);
+  const int nbf = nb / unit * unit;
+  if (nbf >= hmmc_num_cus() * 4) {
+    hipLaunchKernelGGL(vit_embed_ln_kernel<true>, dim3(nbf), dim3(256), 0, stream, (half_t*)x0, cls, pos, gamma, beta, (half_t*)y,
+                       mean, rstd, stat, rows, L, D, eps, eps, write_x0);
+  } else {
+    hipLaunchKernelGGL(vit_embed_ln_kernel<false>, dim3(nb), dim3(256), 0, stream, (half_t*)x0, cls, pos, gamma, beta, (half_t*)y,
+                       mean, rstd, stat, rows, L, D, eps, eps, write_x0);
+  }
   return hmmc_launch_status();
 }
 

@@ -161,7 +161,8 @@ def test_both_towers_folded_against_both_regimes_of_the_reference(monkeypatch):
         assert nrm(mine, ga[key]) <= 1.5 * own_l2, key
 
 
-@pytest.mark.parametrize("nframes,L,D", [(37, 50, 768), (5, 197, 768), (9, 10, 128)])
+@pytest.mark.parametrize("nframes,L,D", [(37, 50, 768), (5, 197, 768), (9, 10, 128),
+                                         (700, 50, 768), (200, 197, 768)])    # enough rows for the one-position-per-wave grid (round 5)
 def test_vit_embed_ln_is_bit_identical_to_its_two_stages(nframes, L, D):
     """hmmc_vit_embed_ln = hmmc_vit_embed + hmmc_layernorm_fwd (modules/module_clip.py:311-313) in one pass: same bits, plus
     the row pairs of its output."""
