@@ -82,6 +82,7 @@ SIGNATURES = {
     "hmmc_mt_bertadam_ext": ("ppipiippp", "i"),
     "hmmc_mt_ema": ("ppiffp", "i"),
     "hmmc_enqueue": ("ppiillp", "i"),
+    "hmmc_bn_finalize": ("ppfffppppppip", "i"),
     "hmmc_bn_workspace": ("ii", "z"),
     "hmmc_bn_stats": ("ppiipzp", "i"),
     "hmmc_bn_apply_relu": ("ppppppli p".replace(" ", ""), "i"),

@@ -90,6 +90,31 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   }
 }
 
+// Batch statistics of BatchNorm1d from the column sums, and the running statistics of train mode, in one launch (round 5: the
+// host side spent 14 elementwise launches on these [N]-sized vectors per MLP call): mean = s1 / n, var = max(s2 / n - mean^2, 0)
+// (biased: what normalises), rstd = rsqrt(var + eps); running_mean = (1 - mom) running_mean + mom mean, running_var likewise
+// with the unbiased var n / (n - 1) (torch.nn.BatchNorm1d), num_batches_tracked += 1.  n = *n_dev (the all-reduced row count of
+// SyncBatchNorm) or n_host.  The arithmetic follows the tensor expressions op by op (separate roundings, no fused contraction).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ n_dev, float n_host,
+                                                          float eps, float mom, float* __restrict__ mean, float* __restrict__ var,
+                                                          float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, long* __restrict__ nbt, int N) {
+  const float n = n_dev ? n_dev[0] : n_host;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col == 0 && nbt) nbt[0] += 1;
+  if (col >= N) return;
+  const float m = sums[col] / n;
+  const float v = fmaxf(opq(sums[N + col] / n) - opq(m * m), 0.0f);
+  mean[col] = m;
+  var[col] = v;
+  rstd[col] = 1.0f / sqrtf(v + eps);              // torch.rsqrt on the GPU: correctly rounded 1 / sqrt here, within 1 ulp of it
+  if (run_mean) {
+    const float nm1 = fmaxf(n - 1.0f, 1.0f);
+    run_mean[col] = opq(run_mean[col] * (1.0f - mom)) + opq(mom * m);
+    run_var[col] = opq(run_var[col] * (1.0f - mom)) + opq(mom * opq(v * opq(n / nm1)));
+  }
+}
+
 // dh = gamma * rstd * (d - sum_d/n - xhat * sum_dx/n), d = dy * (y > 0); n = global row count
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ h, const float* __restrict__ mean,
@@ -301,6 +326,15 @@ extern "C" int hmmc_bn_bwd_apply(const float* dy, const float* y, const float* h
   if (!dy || !y || !h || !mean || !rstd || !gamma || !sums || !dh || M <= 0) return HMMC_ERR_ARG;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(M * N)), dim3(256), 0, stream, dy, y, h, mean, rstd, gamma, sums, dh, M, N,
                      inv_n);
+  return hmmc_launch_status();
+}
+
+extern "C" int hmmc_bn_finalize(const float* sums, const float* n_dev, float n_host, float eps, float momentum, float* mean,
+                                float* var, float* rstd, float* running_mean, float* running_var, long* num_batches_tracked, int N,
+                                hipStream_t stream) {
+  if (!sums || !mean || !var || !rstd || N <= 0 || (!n_dev && !(n_host > 0.f)) || (!running_mean != !running_var)) return HMMC_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, sums, n_dev, n_host, eps, momentum, mean, var, rstd,
+                     running_mean, running_var, num_batches_tracked, N);
   return hmmc_launch_status();
 }
 

@@ -484,25 +484,32 @@ class MlpFn(torch.autograd.Function):
     (reference MLP, modules/modeling.py:788-807).  Returns (y, batch_mean, batch_var_biased, n_rows_global)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, gamma, beta, w2, b2, eps):
+    def forward(ctx, x, w1, b1, gamma, beta, w2, b2, eps, running=None):
+        """running: (running_mean, running_var, num_batches_tracked, momentum) of the BatchNorm1d to update in place (train mode)."""
         x = x.contiguous()
         h = ops.linear_f32(x, w1, bias=b1)
         sums = ops.bn_stats(h)
-        n_local = torch.full((1,), float(h.shape[0]), device=h.device)      # a fill kernel: torch.tensor(..., device=) is a blocking copy
-        packed = _sync_sum(torch.cat([sums.view(-1), n_local]))
-        n = packed[-1]
-        mean = packed[:h.shape[1]] / n
-        var = (packed[h.shape[1]:-1] / n - mean * mean).clamp_min(0.0)
-        rstd = torch.rsqrt(var + eps)
-        y = ops.bn_apply_relu(h, mean.contiguous(), rstd.contiguous(), gamma, beta)
+        N = h.shape[1]
+        if collectives_active():
+            n_local = torch.full((1,), float(h.shape[0]), device=h.device)      # a fill kernel: torch.tensor(..., device=) is a blocking copy
+            packed = _sync_sum(torch.cat([sums.view(-1), n_local]))
+            n = packed[-1:]                                                      # the global row count, on the device
+            sums = packed[:-1].view(2, N)
+        else:
+            n = float(h.shape[0])
+        rm, rv, nbt, mom = running if running is not None else (None, None, None, 0.0)
+        mean, var, rstd = ops.bn_finalize(sums, n, eps, mom, rm, rv, nbt)        # one launch: statistics + running statistics
+        y = ops.bn_apply_relu(h, mean, rstd, gamma, beta)
         out = ops.linear_f32(y, w2, bias=b2)
-        ctx.save_for_backward(x, w1, gamma, w2, h, y, mean, rstd, n)
-        ctx.mark_non_differentiable(mean, var, n)
-        return out, mean, var, n
+        ctx.n = n
+        ctx.save_for_backward(x, w1, gamma, w2, h, y, mean, rstd)
+        ctx.mark_non_differentiable(mean, var)
+        return out, mean, var
 
     @staticmethod
-    def backward(ctx, dout, _dm, _dv, _dn):
-        x, w1, gamma, w2, h, y, mean, rstd, n = ctx.saved_tensors
+    def backward(ctx, dout, _dm, _dv):
+        x, w1, gamma, w2, h, y, mean, rstd = ctx.saved_tensors
+        n = ctx.n
         dout = dout.contiguous()
         dw2 = ops.wgrad_f32(dout, y)
         db2 = ops.colsum(dout)
@@ -510,14 +517,17 @@ class MlpFn(torch.autograd.Function):
         local = ops.bn_bwd_reduce(dy, y, h, mean, rstd)
         # dgamma / dbeta are this rank's sums (DDP averages parameter gradients afterwards, as with SyncBatchNorm);
         # dx needs the sums over every rank's rows
-        dbeta, dgamma = local[0].clone(), local[1].clone()
-        sums = _sync_sum(local.clone()) if collectives_active() else local
-        # sums / n on the device (n is the all-reduced row count): reading n on the host would stall the launch stream
-        dh = ops.bn_bwd_apply(dy, y, h, mean, rstd, gamma, (sums / n).contiguous(), n_global=1.0)
+        dbeta, dgamma = local[0], local[1]
+        if collectives_active():
+            # sums / n on the device (n is the all-reduced row count): reading n on the host would stall the launch stream
+            sums = _sync_sum(local.clone())
+            dh = ops.bn_bwd_apply(dy, y, h, mean, rstd, gamma, (sums / n).contiguous(), n_global=1.0)
+        else:
+            dh = ops.bn_bwd_apply(dy, y, h, mean, rstd, gamma, local, n_global=n)
         dw1 = ops.wgrad_f32(dh, x)
         db1 = ops.colsum(dh)
         dx = ops.dgrad_f32(dh, w1)
-        return dx, dw1, db1, dgamma, dbeta, dw2, db2, None
+        return dx, dw1, db1, dgamma, dbeta, dw2, db2, None, None
 
 
 class MocoLossFn(torch.autograd.Function):

@@ -554,10 +554,7 @@ class MLP(nn.Module):
             h = ops.linear_f32(x2.contiguous(), lin1.weight, bias=lin1.bias)
             y = ops.bn_apply_relu(h, bn.running_mean, torch.rsqrt(bn.running_var + bn.eps), bn.weight, bn.bias)
             return ops.linear_f32(y, lin2.weight, bias=lin2.bias).view(*lead, -1)
-        out, mean, var, n = Fn.MlpFn.apply(x2, lin1.weight, lin1.bias, bn.weight, bn.bias, lin2.weight, lin2.bias, bn.eps)
-        with torch.no_grad():
-            mom = bn.momentum
-            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(var * (n / (n - 1).clamp(min=1.0)), alpha=mom)
-            bn.num_batches_tracked += 1
+        # the running statistics are updated by the same launch that forms the batch statistics (hmmc_bn_finalize)
+        out, mean, var = Fn.MlpFn.apply(x2, lin1.weight, lin1.bias, bn.weight, bn.bias, lin2.weight, lin2.bias, bn.eps,
+                                        (bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum))
         return out.view(*lead, -1)

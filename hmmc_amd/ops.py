@@ -680,6 +680,25 @@ def bn_stats(h):
     return sums
 
 
+def bn_finalize(sums, n, eps, momentum=0.0, running_mean=None, running_var=None, num_batches_tracked=None):
+    """sums [2, N] (hmmc_bn_stats, summed over ranks) -> (mean, biased var, rstd); n: the global row count, a python number or a
+    one-element device tensor.  With running_mean / running_var the train-mode running statistics are updated in place."""
+    N = sums.shape[-1] if sums.dim() == 2 else sums.numel() // 2
+    _chk(sums, torch.float32, "sums")
+    out = torch.empty((3, N), dtype=torch.float32, device=sums.device)
+    n_dev, n_host = (n, 0.0) if isinstance(n, torch.Tensor) else (None, float(n))
+    if n_dev is not None:
+        _chk(n_dev, torch.float32, "n")
+    for t in (running_mean, running_var):
+        if t is not None:
+            _chk(t, torch.float32, "running statistics")
+    if num_batches_tracked is not None:
+        _chk(num_batches_tracked, torch.int64, "num_batches_tracked")
+    call("hmmc_bn_finalize", ptr(sums), ptr(n_dev), n_host, float(eps), float(momentum), ptr(out[0]), ptr(out[1]), ptr(out[2]),
+         ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), N)
+    return out[0], out[1], out[2]
+
+
 def bn_apply_relu(h, mean, rstd, gamma, beta):
     M, N = h.shape
     y = torch.empty_like(h)

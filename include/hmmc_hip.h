@@ -319,6 +319,12 @@ int hmmc_enqueue(const float* keys, float* queue, int R, int E, long W, long col
  * hmmc_bn_apply_relu: y = relu((h - mean) * rstd * gamma + beta);
  * hmmc_bn_bwd_reduce: sums[0] = sum d, sums[1] = sum d * xhat with d = dy * (y > 0);
  * hmmc_bn_bwd_apply: dh = gamma * rstd * (d - sums[0]*inv_n - xhat * sums[1]*inv_n), inv_n = 1 / global row count. */
+/* hmmc_bn_finalize (one launch for the [N]-sized vector arithmetic between hmmc_bn_stats and hmmc_bn_apply_relu): mean = sums[0] / n,
+ * var = max(sums[1] / n - mean^2, 0) (biased), rstd = 1 / sqrt(var + eps), n = *n_dev (device scalar: the row count summed over ranks,
+ * SyncBatchNorm) or n_host when n_dev is NULL; with running_mean / running_var (both or neither) the train-mode update of
+ * nn.BatchNorm1d: running = (1 - momentum) running + momentum x (mean | var n / (n - 1)), *num_batches_tracked += 1 (may be NULL). */
+int hmmc_bn_finalize(const float* sums, const float* n_dev, float n_host, float eps, float momentum, float* mean, float* var,
+                     float* rstd, float* running_mean, float* running_var, long* num_batches_tracked, int N, hmmc_stream_t stream);
 size_t hmmc_bn_workspace(int M, int N);
 int hmmc_bn_stats(const float* h, float* sums, int M, int N, void* workspace, size_t ws_bytes, hmmc_stream_t stream);
 int hmmc_bn_apply_relu(const float* h, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,

@@ -30,7 +30,8 @@ def test_mlp_fn_vs_torch_batchnorm():
     (ref * w).sum().backward()
     P = [p.detach().clone().to(DEV).requires_grad_() for p in (lin1.weight, lin1.bias, bn.weight, bn.bias, lin2.weight, lin2.bias)]
     xg = x.to(DEV).requires_grad_()
-    out, mean, var, n = Fn.MlpFn.apply(xg, *P, bn.eps)
+    rm, rv, nbt = torch.zeros(4096, device=DEV), torch.ones(4096, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+    out, mean, var = Fn.MlpFn.apply(xg, *P, bn.eps, (rm, rv, nbt, bn.momentum))
     (out * w.to(DEV)).sum().backward()
     close(out, ref, 2e-4, 1e-4, "mlp out")
     close(xg.grad, ref_in.grad, 2e-4, 2e-3, "dx")
@@ -38,6 +39,10 @@ def test_mlp_fn_vs_torch_batchnorm():
                               ("w1", "b1", "gamma", "beta", "w2", "b2")):
         close(mine.grad, refp.grad, 3e-4, 2e-3, nm)
     close(mean * 0.1, bn.running_mean, 1e-5, 1e-4, "running mean")
+    # the train-mode running statistics, updated by the same launch (hmmc_bn_finalize), against nn.BatchNorm1d's own
+    close(rm, bn.running_mean, 1e-6, 1e-5, "running_mean")
+    close(rv, bn.running_var, 1e-6, 1e-5, "running_var")
+    assert int(nbt) == int(bn.num_batches_tracked) == 1
 
 
 @pytest.mark.parametrize("R,Kq", [(4, 16), (24, 64), (16, 64), (40, 192), (352, 12288)])
