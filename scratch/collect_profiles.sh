@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 run_stats() {   # name, bench args...
   local name=$1; shift
   rm -rf /tmp/prof_$name
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-hbm-roofline "$@" > $OUT/$name.log 2>&1
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-hbm-roofline --unfolded-steps 0 "$@" > $OUT/$name.log 2>&1
   cp $(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1) $OUT/$name.csv
   echo "$name: $(tail -1 $OUT/$name.log | cut -c1-160)"
 }
@@ -19,16 +19,18 @@ run_stats ${TAG}_bench_b256_kernel_stats_single_stream --steps 4 --warmup 2 --ro
 run_stats ${TAG}_bench_b256_kernel_stats --steps 4 --warmup 2 --roofline-steps 1 --vit-forward-iters 0
 run_stats ${TAG}_bench_pretrain_b128_kernel_stats_single_stream --mode pretrain --steps 4 --warmup 2 --roofline-steps 1 --single-stream --vit-forward-iters 0
 run_stats ${TAG}_bench_vitb16_b16_f24_kernel_stats_single_stream --clip ViT-B/16 --frames 24 --batch 16 --steps 4 --warmup 2 --roofline-steps 1 --single-stream --vit-forward-iters 0
+# the fp32 regime (model.float(): the regime whose logits are held to 1e-3), round 5
+run_stats ${TAG}_bench_fp32_b256_kernel_stats_single_stream --regime fp32 --steps 2 --warmup 1 --roofline-steps 1 --single-stream
 # b = 32 with the per-step breakdown (kernel trace)
 rm -rf /tmp/prof_b32
-rocprofv3 --kernel-trace --stats -d /tmp/prof_b32 -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-hbm-roofline --batch 32 --steps 6 --warmup 2 --roofline-steps 0 --single-stream --vit-forward-iters 0 > $OUT/${TAG}_b32.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_b32 -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-hbm-roofline --batch 32 --steps 6 --warmup 2 --roofline-steps 0 --single-stream --vit-forward-iters 0 --unfolded-steps 0 --reserve-cus 16 > $OUT/${TAG}_b32.log 2>&1
 cp $(find /tmp/prof_b32 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_b32_kernel_stats_single_stream.csv
 python3 $R/scratch/trace_gaps.py $(find /tmp/prof_b32 -name "*kernel_trace.csv" | head -1) 45 > $OUT/${TAG}_bench_b32_kernel_breakdown_single_stream.txt 2>&1
 rm -rf /tmp/prof_b32o
-rocprofv3 --kernel-trace --stats -d /tmp/prof_b32o -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-hbm-roofline --batch 32 --steps 6 --warmup 2 --roofline-steps 0 --vit-forward-iters 0 > $OUT/${TAG}_b32o.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_b32o -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-hbm-roofline --batch 32 --steps 6 --warmup 2 --roofline-steps 0 --vit-forward-iters 0 --unfolded-steps 0 --reserve-cus 16 > $OUT/${TAG}_b32o.log 2>&1
 python3 $R/scratch/trace_gaps.py $(find /tmp/prof_b32o -name "*kernel_trace.csv" | head -1) 45 > $OUT/${TAG}_bench_b32_kernel_breakdown.txt 2>&1
 # HBM traffic of gemm_f16_kernel: separate passes per counter, kernel trace only
-CMD="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-roofline --roofline-steps 0 --vit-forward-iters 0"
+CMD="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-roofline --roofline-steps 0 --vit-forward-iters 0 --unfolded-steps 0"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p --output-format csv -- python3 $R/bench.py $CMD > $OUT/pmc_$c.log 2>&1

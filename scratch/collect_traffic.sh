@@ -5,7 +5,7 @@ TAG=${1:-r04}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-roofline --roofline-steps 0 --vit-forward-iters 0"
+CMD="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-roofline --roofline-steps 0 --vit-forward-iters 0 --unfolded-steps 0"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p --output-format csv -- python3 $R/bench.py $CMD > $OUT/pmc_$c.log 2>&1
