@@ -662,35 +662,57 @@ struct ReduceTask { const float* partial; int R, N, seg; void* out[3]; int dtype
 constexpr int REDUCE_MAX_TASKS = 48;
 struct ReduceArgs { ReduceTask t[REDUCE_MAX_TASKS]; int off[REDUCE_MAX_TASKS + 1]; int n; };
 
+// A block takes 128 columns of one task (32 lanes x 4 columns: 512 contiguous bytes per row and 32-lane group) and its 8 row
+// lanes walk the rows with four independent 16-byte loads in flight each (round 5; one column per thread and two loads in flight
+// until then: 164 us for the 200 MB of partials of a b = 32 step).  Fixed order: row lane rl sums rows rl, rl + 8, ... in four
+// interleaved accumulators (rows = rl + 8 (4 i + k) -> accumulator k), then k = 0..3, then the row lanes 0..7.
+constexpr int MCR_COLS = 128;
 __global__ __launch_bounds__(256) void multi_colreduce_kernel(ReduceArgs a) {
-  __shared__ float red[8][33];
+  __shared__ f4 red[8][33];
   int ti = 0;
   while (ti + 1 < a.n && (int)blockIdx.x >= a.off[ti + 1]) ++ti;           // block-uniform
   const ReduceTask& t = a.t[ti];
   const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int col = ((int)blockIdx.x - a.off[ti]) * 32 + c;
+  const int col = ((int)blockIdx.x - a.off[ti]) * MCR_COLS + 4 * c;
   const float* P = t.partial;
   const int R = t.R, N = t.N;
-  float a0 = 0.f, a1 = 0.f;
+  const bool vec = (N & 3) == 0 && col + 3 < N && ((uintptr_t)P & 15) == 0;    // 16-byte aligned rows: one f4 load per row
+  f4 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
+  auto load = [&](int r) -> f4 {
+    const float* pr = P + (long)r * N + col;
+    if (vec) return *reinterpret_cast<const f4*>(pr);
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (col + j < N) v[j] = pr[j];
+    return v;
+  };
   if (col < N) {
     int r = rl;
-    for (; r + 8 < R; r += 16) {
-      a0 += P[(long)r * N + col];
-      a1 += P[(long)(r + 8) * N + col];
+    for (; r + 24 < R; r += 32) {
+      const f4 v0 = load(r), v1 = load(r + 8), v2 = load(r + 16), v3 = load(r + 24);
+      acc[0] += v0; acc[1] += v1; acc[2] += v2; acc[3] += v3;
     }
-    if (r < R) a0 += P[(long)r * N + col];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (r + 8 * k < R) acc[k] += load(r + 8 * k);
   }
-  red[rl][c] = a0 + a1;
+  red[rl][c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   __syncthreads();
   if (rl == 0 && col < N) {
-    float v = 0.f;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) v += red[k][c];
-    const int sgm = col / t.seg, pos = col - sgm * t.seg;
-    void* o = t.out[sgm];
-    if (o) {
-      if (t.dtype[sgm] == 0) reinterpret_cast<half_t*>(o)[pos] = (half_t)v;
-      else reinterpret_cast<float*>(o)[pos] = v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cj = col + j;
+      if (cj >= N) break;
+      const int sgm = cj / t.seg, pos = cj - sgm * t.seg;
+      void* o = t.out[sgm];
+      if (o) {
+        if (t.dtype[sgm] == 0) reinterpret_cast<half_t*>(o)[pos] = (half_t)v[j];
+        else reinterpret_cast<float*>(o)[pos] = v[j];
+      }
     }
   }
 }
@@ -957,7 +979,7 @@ extern "C" int hmmc_multi_colreduce(const void* tasks_host, int ntasks, hipStrea
       if (!t.partial || t.R <= 0 || t.N <= 0 || t.seg <= 0 || (t.N + t.seg - 1) / t.seg > 3) return HMMC_ERR_ARG;
       a.t[i] = t;
       a.off[i] = blocks;
-      blocks += (t.N + 31) / 32;
+      blocks += (t.N + MCR_COLS - 1) / MCR_COLS;
     }
     a.off[a.n] = blocks;
     hipLaunchKernelGGL(multi_colreduce_kernel, dim3(blocks), dim3(256), 0, stream, a);

@@ -432,6 +432,42 @@ def test_attention_query0_only_equals_the_all_query_kernels(nseq, L, H, causal):
     assert torch.equal(d2[:, D:], dsc[:, D:]) and torch.equal(d2[lead, :D], dsc[lead, :D]), "scaled rows"
 
 
+def test_multi_colreduce_many_tasks_ragged_and_unaligned():
+    """hmmc_multi_colreduce (round 5: 128 columns per block, 16-byte loads where the rows allow): several tasks in one launch -
+    widths that are / are not multiples of 4 and of 128, a partial matrix at an address that is not 16-byte aligned, one to three
+    output segments in fp16 / fp32, a missing (NULL) segment, row counts from 1 to 700 - against float64 column sums."""
+    import ctypes
+    from hmmc_amd import _lib
+
+    class Task(ctypes.Structure):
+        _fields_ = [("partial", ctypes.c_void_p), ("R", ctypes.c_int), ("N", ctypes.c_int), ("seg", ctypes.c_int),
+                    ("out", ctypes.c_void_p * 3), ("dtype", ctypes.c_int * 3)]
+    g = torch.Generator(device=DEV).manual_seed(17)
+    specs = [(600, 2304, 768, (1, 1, 0)), (150, 3072, 3072, (0,)), (384, 2304, 2304, (0,)), (1, 130, 130, (1,)), (7, 1026, 342, (1, None, 0)),
+             (700, 512, 256, (0, 1)), (33, 96, 96, (1,)), (257, 100, 100, (0,))]
+    keep, tasks, checks = [], (Task * len(specs))(), []
+    for i, (R, N, seg, outs) in enumerate(specs):
+        buf = torch.randn(R * N + 1, device=DEV, generator=g)
+        part = buf[1:] if i % 3 == 2 else buf[:-1]                 # every third partial matrix starts 4 bytes off a 16-byte boundary
+        keep.append(buf)
+        tasks[i].partial, tasks[i].R, tasks[i].N, tasks[i].seg = part.data_ptr(), R, N, seg
+        ref = part.view(R, N).double().sum(0)
+        for sgm, dt in enumerate(outs):
+            if dt is None:
+                tasks[i].out[sgm], tasks[i].dtype[sgm] = None, 1
+                continue
+            o = torch.full((seg,), float("nan"), dtype=torch.float16 if dt == 0 else torch.float32, device=DEV)
+            keep.append(o)
+            tasks[i].out[sgm], tasks[i].dtype[sgm] = o.data_ptr(), dt
+            checks.append((o, ref[sgm * seg:(sgm + 1) * seg], dt, (R, N, seg, sgm)))
+    _lib.call("hmmc_multi_colreduce", ctypes.cast(tasks, ctypes.c_void_p), len(specs))
+    torch.cuda.synchronize()
+    for o, ref, dt, what in checks:
+        tol = 2e-3 if dt == 0 else 1e-5
+        err = float((o.double() - ref).abs().max() / (ref.abs().max() + 1e-9))
+        assert err < tol, (what, err)
+
+
 def test_retrieval_rank_ties_and_targets():
     """metrics.py:20-28: the rank is the first position of the target's score in the descending sort."""
     torch.manual_seed(3)
