@@ -846,6 +846,30 @@ def test_class_token_gradient_buffer_is_not_zero_filled_and_not_read(monkeypatch
     assert not bad, bad[:5]
 
 
+def test_tower_release_gives_back_the_event_sets_and_the_next_backward_recreates_them():
+    """hmmc_tower_release (round 5): the seven events a (stream, weight-gradient stream) pair got on its first hmmc_tower_bwd call
+    are destroyed on request; the pair's next backward creates a fresh set and computes the same bits."""
+    from hmmc_amd import _lib
+    model, sd = build(synth.TINY)
+    batch = [t.to(DEV) for t in synth.finetune_batch(4, 4, 32, tag="release")]
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        loss = model(*batch, 1)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None]
+
+    l0, g0 = run()
+    lib = _lib.load()
+    n = lib.hmmc_tower_release(None, None)                   # every pair: nothing of this process is in flight (synchronised above)
+    assert n >= 1, "the backward above used a weight-gradient stream: at least one pair had its events"
+    assert lib.hmmc_tower_release(None, None) == 0
+    l1, g1 = run()
+    assert torch.equal(l0, l1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    assert lib.hmmc_tower_release(None, None) >= 1
+
+
 def _clip_skip_then_step(shared, via_optimizer_zero_grad):
     """clip, NO step (a skipped iteration), gradients dropped, new gradients (other values, version 0 again, and - the caching
     allocator being what it is - at the old addresses), step WITHOUT a clip."""
