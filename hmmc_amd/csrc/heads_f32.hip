@@ -75,18 +75,34 @@ __global__ __launch_bounds__(64) void infonce_rowlse_kernel(const float* __restr
   if (lane == 0) lse_row[(long)i * (1 + F) + blk] = m + __logf(s);
 }
 
-// column LSE: lse_col[c] = log sum_i exp(S[i][c])   (online max/sum, coalesced over c)
+// column LSE: lse_col[c] = log sum_i exp(S[i][c]).  A block takes 32 columns; its 8 row lanes run the online max / sum over rows
+// rl, rl + 8, ... (128-byte coalesced per 32-lane group) and their (max, sum) pairs are merged in row-lane order - a fixed order,
+// so the result is bit-stable.  (Round 5: one thread per column walked all B rows in one dependent chain - 72 us for the
+// 256 x 3 328 matrix of config 2 on 13 workgroups.)
 __global__ __launch_bounds__(256) void infonce_collse_kernel(const float* __restrict__ S, float* __restrict__ lse_col,
                                                              int B, long C) {
-  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sm[8][32], ss[8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const long c = (long)blockIdx.x * 32 + cl;
   float m = -INFINITY, s = 0.f;
-  for (int i = 0; i < B; ++i) {
-    float v = S[(long)i * C + c];
-    if (v > m) { s = s * __expf(m - v) + 1.0f; m = v; }
-    else s += __expf(v - m);
+  if (c < C) {
+    for (int i = rl; i < B; i += 8) {
+      const float v = S[(long)i * C + c];
+      if (v > m) { s = s * __expf(m - v) + 1.0f; m = v; }
+      else s += __expf(v - m);
+    }
   }
-  lse_col[c] = m + __logf(s);
+  sm[rl][cl] = m; ss[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float M = sm[0][cl];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) M = fmaxf(M, sm[k][cl]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += ss[k][cl] > 0.f ? ss[k][cl] * __expf(sm[k][cl] - M) : 0.f;     // a row lane without rows: (-inf, 0)
+    lse_col[c] = M + __logf(t);
+  }
 }
 
 // loss = sum_blk w_blk/B * [ sum_i (lse_row[i][blk] - S[i][col(i,blk)]) + sum_b (lse_col[col(b,blk)] - S[b][col(b,blk)]) ]
@@ -431,7 +447,7 @@ extern "C" int hmmc_infonce_fwd(const float* S, float* lse_row, float* lse_col, 
   if (!S || !lse_row || !lse_col || !loss || B <= 0 || F < 0) return HMMC_ERR_ARG;
   long C = (long)B * (1 + F);
   hipLaunchKernelGGL(infonce_rowlse_kernel, dim3(B, 1 + F), dim3(64), 0, stream, S, lse_row, B, F);
-  hipLaunchKernelGGL(infonce_collse_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, S, lse_col, B, C);
+  hipLaunchKernelGGL(infonce_collse_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, stream, S, lse_col, B, C);
   hipLaunchKernelGGL(infonce_loss_kernel, dim3(1), dim3(256), 0, stream, S, (const float*)lse_row, (const float*)lse_col,
                      loss, B, F, w_video, w_frame);
   return hmmc_launch_status();
