@@ -57,3 +57,17 @@ def test_packed_allgather_and_effective_gradient():
         assert torch.allclose(o["dq"], q.grad[sl], atol=1e-6)
         assert torch.allclose(o["dv"], v.grad[sl], atol=1e-6)
         assert torch.allclose(o["du"], u.grad[sl], atol=1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allgathercat_exact_on_integer_data(world):
+    """The worker of tests/test_gpu_rccl_multi.py::test_allgathercat_is_exact_on_rccl on the gloo backend with CPU tensors: forward =
+    the ranks' rows in rank order, backward = the exact sum over ranks of the gradient rows that belong to this rank (integer-valued
+    data: no rounding), `dist_collect` and the SyncBatchNorm sum likewise.  Keeps the RCCL test's expected values honest on a
+    box without a second GPU."""
+    import test_gpu_rccl_multi as R
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(R._gather_worker, args=(world, os.path.join(d, "s"), d, "gloo"), nprocs=world, join=True)
+        for r in range(world):
+            res = torch.load(os.path.join(d, f"g{r}.pt"))
+            assert all(res.values()), (r, res)

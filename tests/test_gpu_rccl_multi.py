@@ -26,26 +26,34 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(NDEV < 2, reason="needs two GP
 import test_gpu_ddp as D  # noqa: E402
 
 
-def _gather_worker(rank, world, store, out_dir):
-    D._init(rank, world, store, "nccl")
+def _gather_worker(rank, world, store, out_dir, backend="nccl"):
+    """backend "gloo": the same statements on CPU tensors (tests/test_dist_gloo.py runs that here, so the expected values of the
+    RCCL test are themselves tested where no second GPU exists)."""
+    if backend == "nccl":
+        D._init(rank, world, store, "nccl")
+    else:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
+    dev = "cuda" if backend == "nccl" else "cpu"
     import hmmc_amd.functional as Fn
     import hmmc_amd.modeling as M
-    assert Fn.collectives_active() and M._AllGatherCat._flat()
+    assert Fn.collectives_active() and M._AllGatherCat._flat() == (backend == "nccl")
     b, C = 6, 14 * 512                                            # the packed feature row of F = 12: (F + 2) * 512
     g = torch.Generator().manual_seed(77)
     xs = [torch.randint(-64, 64, (b, C), generator=g).float() for _ in range(world)]        # integer data: fp32 sums are exact
     ws = [torch.randint(-8, 8, (world * b, C), generator=g).float() for _ in range(world)]
-    x = xs[rank].cuda().requires_grad_()
+    x = xs[rank].to(dev).requires_grad_()
     y = M._AllGatherCat.apply(x * 1.0)
-    (y * ws[rank].cuda()).sum().backward()
-    torch.cuda.synchronize()
+    (y * ws[rank].to(dev)).sum().backward()
+    if dev == "cuda":
+        torch.cuda.synchronize()
     want_y = torch.cat(xs, 0)
     want_g = sum(w[rank * b:(rank + 1) * b] for w in ws)          # d/dx_r of sum_r' <gather(x), w_r'>: every rank's weights on my rows
     res = {"fwd": bool(torch.equal(y.detach().cpu(), want_y)), "bwd": bool(torch.equal(x.grad.cpu(), want_g))}
-    yc = M.dist_collect(xs[rank].cuda())
+    yc = M.dist_collect(xs[rank].to(dev))
     res["collect"] = bool(torch.equal(yc.cpu(), want_y))
     t = torch.arange(2 * 4096 + 1, dtype=torch.float32) * (rank + 1)
-    res["sync_sum"] = bool(torch.equal(Fn._sync_sum(t.cuda()).cpu(), torch.arange(2 * 4096 + 1, dtype=torch.float32) * (world * (world + 1) // 2)))
+    res["sync_sum"] = bool(torch.equal(Fn._sync_sum(t.to(dev)).cpu(), torch.arange(2 * 4096 + 1, dtype=torch.float32) * (world * (world + 1) // 2)))
     torch.save(res, os.path.join(out_dir, f"g{rank}.pt"))
     dist.destroy_process_group()
 
