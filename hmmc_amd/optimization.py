@@ -191,21 +191,27 @@ class BertAdam(Optimizer):
     # every parameter has a gradient and the parameters of a group share their step count, the static part of the table (weights,
     # moments, sizes, group index) is kept and a step only reads the gradient pointers and evaluates the schedule per group.
     def _plan_fast_path(self, n_rows, steps_per_group):
-        """steps_per_group: {group index: set of the step counts its parameters had in the slow step just taken}."""
+        """steps_per_group: {group index: set of the step counts its parameters had in the slow step just taken}.
+        The plan covers the parameters that HAD a gradient in that step; the others (the pre-training model's t_projector, built and
+        never used, reference modules/modeling.py:113-114; the momentum encoders, requires_grad False) are remembered as `idle` and
+        the fast path holds only while exactly they have none - round 5: the pre-training step never took the fast path before."""
         self._fast = None
-        groups = [g for g in self.param_groups if g["params"]]
-        params = [p for g in groups for p in g["params"]]
-        if n_rows != len(params) or len(groups) > 32 or any(len(s) != 1 for s in steps_per_group.values()):
-            return                                   # some gradient was None, or a group's parameters differ in step count
+        groups = [g for g in self.param_groups if any(p.grad is not None for p in g["params"])]
+        params = [p for g in groups for p in g["params"] if p.grad is not None]
+        idle = [p for g in self.param_groups for p in g["params"] if p.grad is None]
+        if n_rows != len(params) or not params or len(groups) > 32 or any(len(s) != 1 for s in steps_per_group.values()):
+            return                                   # a group's parameters differ in step count
         static = np.zeros((len(params), 7), dtype=np.int64)
         row = 0
         for gi, g in enumerate(groups):
             for p in g["params"]:
+                if p.grad is None:
+                    continue
                 st = self.state[p]
                 static[row] = (p.data_ptr(), 0, st["next_m"].data_ptr(), st["next_v"].data_ptr(), p.numel(), _dtype_flag(p), gi)
                 row += 1
-        self._fast = {"groups": groups, "params": params, "static": static, "states": [self.state[p] for p in params],
-                      "table": _TensorTable(params[0].device)}
+        self._fast = {"groups": groups, "params": params, "idle": idle, "static": static, "states": [self.state[p] for p in params],
+                      "table": _TensorTable(params[0].device), "n_total": sum(len(g["params"]) for g in self.param_groups)}
 
     def _fast_step(self):
         fp = getattr(self, "_fast", None)
@@ -213,7 +219,8 @@ class BertAdam(Optimizer):
             return False
         grads = [p.grad for p in fp["params"]]
         ps, static = fp["params"], fp["static"]
-        if any(g is None for g in grads) or sum(len(g["params"]) for g in self.param_groups) != len(grads):
+        if (any(g is None for g in grads) or any(p.grad is not None for p in fp["idle"])
+                or sum(len(g["params"]) for g in self.param_groups) != fp["n_total"]):
             self._fast = None
             return False
         # parameters moved / a moment tensor was replaced: every pointer is compared, as one array each
@@ -226,7 +233,7 @@ class BertAdam(Optimizer):
             return False
         hp = []
         for g in fp["groups"]:
-            steps = {self.state[p]["step"] for p in g["params"]}
+            steps = {self.state[p]["step"] for p in g["params"] if p.grad is not None}
             if len(steps) != 1:
                 self._fast = None
                 return False

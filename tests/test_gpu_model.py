@@ -870,6 +870,53 @@ def test_tower_release_gives_back_the_event_sets_and_the_next_backward_recreates
     assert lib.hmmc_tower_release(None, None) >= 1
 
 
+def test_fast_path_with_parameters_that_never_get_a_gradient():
+    """The pre-training model hands BertAdam parameters that never receive a gradient (t_projector is built and never used,
+    reference modules/modeling.py:113-114; the momentum encoders do not require grad).  Round 5: the steady-state fast path of
+    step() covers the parameters that do get one and holds while exactly the others stay without; results must be bit-identical
+    to an optimizer that was never given the idle parameters, and a gradient turning up on an idle parameter must fall back."""
+    from hmmc_amd.optimization import BertAdam, clip_grad_norm_
+    g = torch.Generator().manual_seed(31)
+    sizes = [(40000, torch.float16), (77, torch.float32), (32768, torch.float16), (1000, torch.float32), (4096, torch.float16)]
+
+    def make():
+        return [torch.nn.Parameter((torch.randn(n, generator=torch.Generator().manual_seed(100 + i)) * 0.1).to(dt).to(DEV))
+                for i, (n, dt) in enumerate(sizes)]
+    ps_a, ps_b = make(), make()
+    idle = [1, 3]                                                  # these never get a gradient
+    live_b = [p for i, p in enumerate(ps_b) if i not in idle]
+    kw = dict(lr=1e-3, warmup=0.1, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6, t_total=50, max_grad_norm=1.0)
+    opt_a = BertAdam([{"params": ps_a[:3], "weight_decay": 0.01}, {"params": ps_a[3:], "weight_decay": 0.0}], **kw)
+    opt_b = BertAdam([{"params": [ps_b[0], ps_b[2]], "weight_decay": 0.01}, {"params": [ps_b[4]], "weight_decay": 0.0}], **kw)
+    for step in range(4):
+        grads = [(torch.randn(n, generator=g) * 2.0).to(dt).to(DEV) for n, dt in sizes]
+        for i, (pa, pb) in enumerate(zip(ps_a, ps_b)):
+            pa.grad = None if i in idle else grads[i].clone()
+            pb.grad = None if i in idle else grads[i].clone()
+        clip_grad_norm_(ps_a, 1.0)
+        clip_grad_norm_(live_b, 1.0)
+        opt_a.step()
+        opt_b.step()
+        if step >= 1:
+            assert opt_a._fast is not None and len(opt_a._fast["idle"]) == 2, "the fast path must hold with idle parameters"
+    torch.cuda.synchronize()
+    for i, (pa, pb) in enumerate(zip(ps_a, ps_b)):
+        assert torch.equal(pa, pb), i
+        if i not in idle:
+            assert torch.equal(opt_a.state[pa]["next_m"], opt_b.state[pb]["next_m"]) and torch.equal(opt_a.state[pa]["next_v"], opt_b.state[pb]["next_v"])
+            assert opt_a.state[pa]["step"] == 4
+        else:
+            assert len(opt_a.state[pa]) == 0                       # never stepped
+    # an idle parameter gets a gradient: the plan no longer holds, the slow path steps it (its own step count starts at 0)
+    for i, pa in enumerate(ps_a):
+        pa.grad = (torch.randn(sizes[i][0], generator=g) * 0.5).to(sizes[i][1]).to(DEV)
+    before = ps_a[1].detach().clone()
+    opt_a.step()
+    torch.cuda.synchronize()
+    assert opt_a.state[ps_a[1]]["step"] == 1 and opt_a.state[ps_a[0]]["step"] == 5
+    assert torch.equal(ps_a[1], before), "lr is 0 at step 0 of the warm-up: the first update of a late parameter moves nothing"
+
+
 def _clip_skip_then_step(shared, via_optimizer_zero_grad):
     """clip, NO step (a skipped iteration), gradients dropped, new gradients (other values, version 0 again, and - the caching
     allocator being what it is - at the old addresses), step WITHOUT a clip."""
